@@ -1,0 +1,45 @@
+# Top-level build: everything lands in-tree next to its sources.
+#
+#   raytracer_amd/csrc/librt_hip.so   the gfx950 device layer + C ABI (include/rt_hip.h)
+#   raytracer_amd/host/librt_host.so  the C++ host side (scene build) with C entry points
+#   raytracer_amd/host/rt_main        the headless frame-loop executable
+#   oracle/                           the checker (see oracle/Makefile)
+
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+
+CSRC := raytracer_amd/csrc
+HOST := raytracer_amd/host
+
+HIP_SOURCES := $(wildcard $(CSRC)/*.hip)
+HIP_HEADERS := $(wildcard $(CSRC)/*.h) include/rt_hip.h
+HOST_LIB_SOURCES := $(HOST)/model.cpp $(HOST)/scene.cpp $(HOST)/host_capi.cpp
+HOST_HEADERS := $(wildcard $(HOST)/*.h) include/rt_hip.h
+
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -ffp-contract=off -fno-fast-math \
+            -fgpu-rdc=0 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
+CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -I$(HOST)
+
+all: device host oracle
+
+device: $(CSRC)/librt_hip.so
+host: $(HOST)/librt_host.so $(HOST)/rt_main
+oracle:
+	$(MAKE) -C oracle all
+
+$(CSRC)/librt_hip.so: $(HIP_SOURCES) $(HIP_HEADERS)
+	$(HIPCC) $(HIPFLAGS) $(HIP_SOURCES) -o $@
+
+$(HOST)/librt_host.so: $(HOST_LIB_SOURCES) $(HOST_HEADERS)
+	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SOURCES) -o $@
+
+$(HOST)/rt_main: $(HOST)/main.cpp $(HOST)/raytracer.cpp $(HOST)/librt_host.so $(CSRC)/librt_hip.so $(HOST_HEADERS)
+	$(CXX) $(CXXFLAGS) $(HOST)/main.cpp $(HOST)/raytracer.cpp -o $@ \
+	    -L$(HOST) -lrt_host -L$(CSRC) -lrt_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
+
+clean:
+	rm -f $(CSRC)/librt_hip.so $(HOST)/librt_host.so $(HOST)/rt_main
+	$(MAKE) -C oracle clean
+
+.PHONY: all device host oracle clean

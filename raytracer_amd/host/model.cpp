@@ -1,0 +1,414 @@
+// model.cpp -- PLY ingest and wide bounding-box hierarchy build on the host.
+//
+// Restates what the reference does in model.cpp:25-222 (TriangleBlock::subdivide/reserve/fill,
+// Model::load/prepare/put) on index arrays instead of pointer trees, so that the emitted groups,
+// boxes, leaf-local vertices and packed triangles are byte-identical to the reference's for the same
+// mesh.  Build with -ffp-contract=off: every float expression here is evaluated as written.
+
+#include "model.h"
+
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace rt {
+
+// ---------------------------------------------------------------- ResourceManager
+
+void ResourceManager::alloc()
+{
+    assert(!allocated_);
+    groups_.assign(want_[0], rt_group());
+    aabbs_.assign(want_[1], rt_aabb());
+    vertices_.assign(want_[2], rt_vertex());
+    triangles_.assign(want_[3], 0u);
+    std::memset(groups_.data(), 0, groups_.size() * sizeof(rt_group));
+    std::memset(aabbs_.data(), 0, aabbs_.size() * sizeof(rt_aabb));
+    std::memset(vertices_.data(), 0, vertices_.size() * sizeof(rt_vertex));
+    allocated_ = true;
+}
+
+bool ResourceManager::full() const
+{
+    for (int i = 0; i < 4; i++)
+        if (used_[i] != want_[i]) return false;
+    return true;
+}
+
+uint32_t ResourceManager::take(int which, size_t n)
+{
+    if (n && (!allocated_ || used_[which] + n > want_[which]))
+        throw std::logic_error("ResourceManager: request exceeds the reserved size");
+    const uint32_t first = uint32_t(used_[which]);
+    used_[which] += n;
+    return first;
+}
+
+// ---------------------------------------------------------------- camera
+
+void set_camera(rt_camera &cam, size_t width, size_t height, float tan_fov, const Vec3 &pos, const Vec3 &view,
+                const Vec3 &up)
+{
+    const float w = float(width), h = float(height);
+    const float unit = tan_fov / std::sqrt(w * w + h * h);
+    const Vec3 dir = normalized(view);
+    const Vec3 dx = scale(normalized(cross(view, up)), unit);
+    const Vec3 dy = cross(dx, dir);
+    const Vec3 corner = dir - divide(scale(dx, w) + scale(dy, h), 2);
+    store3(cam.eye, pos);
+    store3(cam.top_left, corner);
+    store3(cam.dx, dx);
+    store3(cam.dy, dy);
+    cam.width = uint32_t(width);
+    cam.height = uint32_t(height);
+}
+
+// ---------------------------------------------------------------- PLY ingest
+
+namespace {
+
+// Whitespace-separated token reader over a file held in memory.
+class Tokens {
+public:
+    explicit Tokens(std::vector<char> &&text) : text_(std::move(text)), at_(text_.data()) {}
+
+    bool word(std::string &out)
+    {
+        skip_space();
+        if (!*at_) return false;
+        const char *start = at_;
+        while (*at_ && !is_space(*at_)) at_++;
+        out.assign(start, at_);
+        return true;
+    }
+
+    bool expect(const char *literal)
+    {
+        std::string w;
+        return word(w) && w == literal;
+    }
+
+    void rest_of_line()
+    {
+        while (*at_ && *at_ != '\n') at_++;
+    }
+
+    bool number(float &out)
+    {
+        skip_space();
+        char *end;
+        out = std::strtof(at_, &end);
+        if (end == at_) return false;
+        at_ = end;
+        return true;
+    }
+
+    bool number(size_t &out)
+    {
+        skip_space();
+        if (*at_ < '0' || *at_ > '9') return false;
+        char *end;
+        out = std::strtoull(at_, &end, 10);
+        at_ = end;
+        return true;
+    }
+
+    const char *mark() const { return at_; }
+    void rewind(const char *to) { at_ = to; }
+
+private:
+    static bool is_space(char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t' || c == '\f' || c == '\v'; }
+    void skip_space()
+    {
+        while (is_space(*at_)) at_++;
+    }
+
+    std::vector<char> text_;
+    const char *at_;
+};
+
+bool slurp(const char *file, std::vector<char> &text)
+{
+    FILE *in = std::fopen(file, "rb");
+    if (!in) return false;
+    std::fseek(in, 0, SEEK_END);
+    const long size = std::ftell(in);
+    std::fseek(in, 0, SEEK_SET);
+    if (size < 0) {
+        std::fclose(in);
+        return false;
+    }
+    text.resize(size_t(size) + 1);
+    const size_t got = std::fread(text.data(), 1, size_t(size), in);
+    std::fclose(in);
+    text[got] = '\0';
+    return got == size_t(size);
+}
+
+}  // namespace
+
+bool Model::load(const char *file)
+{
+    if (!pos_.empty() || !faces_.empty()) return false;
+    std::vector<char> text;
+    if (!slurp(file, text)) return false;
+    Tokens tok(std::move(text));
+
+    // Header, in the fixed order the reference's scanf templates demand (model.cpp:145-160).
+    size_t n_vtx = 0, n_tri = 0;
+    if (!tok.expect("ply") || !tok.expect("format") || !tok.expect("ascii") || !tok.expect("1.0")) return false;
+    if (!tok.expect("comment")) return false;
+    tok.rest_of_line();
+    if (!tok.expect("element") || !tok.expect("vertex") || !tok.number(n_vtx) || !n_vtx) return false;
+    for (const char *axis : {"x", "y", "z"})
+        if (!tok.expect("property") || !tok.expect("float") || !tok.expect(axis)) return false;
+    size_t extra = 0;  // further float properties per vertex, skipped when reading
+    for (;;) {
+        const char *here = tok.mark();
+        std::string name;
+        if (tok.expect("property") && tok.expect("float") && tok.word(name)) {
+            extra++;
+            continue;
+        }
+        tok.rewind(here);
+        break;
+    }
+    if (extra > 4) return false;  // the reference's format buffer holds four (model.cpp:143, 166-171)
+    if (!tok.expect("element") || !tok.expect("face") || !tok.number(n_tri) || !n_tri) return false;
+    std::string list_type;
+    if (!tok.expect("property") || !tok.expect("list") || !tok.expect("uchar") || !tok.word(list_type)) return false;
+    if (list_type != "int" && list_type != "uint") return false;
+    if (!tok.expect("vertex_indices") || !tok.expect("end_header")) return false;
+
+    std::vector<Vec3> positions(n_vtx);
+    for (size_t i = 0; i < n_vtx; i++) {
+        float skipped;
+        if (!tok.number(positions[i].x) || !tok.number(positions[i].y) || !tok.number(positions[i].z)) return false;
+        for (size_t k = 0; k < extra; k++)
+            if (!tok.number(skipped)) return false;
+    }
+    std::vector<std::array<uint32_t, 3>> faces(n_tri);
+    for (size_t i = 0; i < n_tri; i++) {
+        size_t corners, v[3];
+        if (!tok.number(corners) || corners != 3) return false;
+        for (int k = 0; k < 3; k++) {
+            if (!tok.number(v[k]) || v[k] >= n_vtx) return false;
+            faces[i][k] = uint32_t(v[k]);
+        }
+    }
+    return assign(positions, faces);
+}
+
+bool Model::assign(const std::vector<Vec3> &positions, const std::vector<std::array<uint32_t, 3>> &faces)
+{
+    if (!pos_.empty() || !faces_.empty() || positions.empty() || faces.empty()) return false;
+    for (const auto &f : faces)
+        for (uint32_t v : f)
+            if (v >= positions.size()) return false;
+    pos_ = positions;
+    faces_.resize(faces.size());
+    for (size_t i = 0; i < faces.size(); i++)
+        for (int k = 0; k < 3; k++) faces_[i].v[k] = faces[i][k];
+    prepare();
+    return true;
+}
+
+// Area-weighted vertex normals, triangle centroids and the centroid bounds of the root (model.cpp:197-214).
+void Model::prepare()
+{
+    norm_.assign(pos_.size(), Vec3(0, 0, 0));
+    slot_.assign(pos_.size(), -1);
+    order_.resize(faces_.size());
+    Bounds centroid_box;
+    for (size_t i = 0; i < faces_.size(); i++) {
+        Face &f = faces_[i];
+        const Vec3 a = pos_[f.v[0]], b = pos_[f.v[1]], c = pos_[f.v[2]];
+        f.center = divide((a + b) + c, 3);
+        const Vec3 n = cross(b - a, c - a);
+        for (int k = 0; k < 3; k++) norm_[f.v[k]] = norm_[f.v[k]] + n;
+        centroid_box.add(f.center);
+        order_[i] = uint32_t(i);
+    }
+    for (size_t i = 0; i < pos_.size(); i++) norm_[i] = divide(norm_[i], length(norm_[i]));
+    nodes_.clear();
+    Node root;
+    root.first = 0;
+    root.count = uint32_t(faces_.size());
+    root.box = centroid_box;
+    nodes_.push_back(root);
+}
+
+// ---------------------------------------------------------------- hierarchy
+
+void Model::subdivide(size_t tri_threshold, size_t aabb_threshold)
+{
+    assert(nodes_.size() == 1);
+    split(0, tri_threshold, aabb_threshold, true);
+}
+
+// Returns how many boxes this subtree contributes to the closest enclosing box group.
+size_t Model::split(int node, size_t tri_threshold, size_t aabb_threshold, bool is_root)
+{
+    const uint32_t first = nodes_[node].first, count = nodes_[node].count;
+    if (count < tri_threshold) return 1;
+
+    const Bounds box = nodes_[node].box;
+    const Vec3 extent = box.hi - box.lo;
+    int axis;
+    if (extent.x > extent.y && extent.x > extent.z) axis = 0;
+    else if (extent.y > extent.z) axis = 1;
+    else axis = 2;
+
+    uint32_t *begin = order_.data() + first;
+    const Face *faces = faces_.data();
+    std::sort(begin, begin + count, [faces, axis](uint32_t a, uint32_t b) { return faces[a].center[axis] < faces[b].center[axis]; });
+
+    const uint32_t half = count / 2;
+    Node lower, upper;
+    lower.first = first;
+    lower.count = half;
+    lower.box = box;
+    lower.box.hi[axis] = faces_[begin[half - 1]].center[axis];
+    upper.first = first + half;
+    upper.count = count - half;
+    upper.box = box;
+    upper.box.lo[axis] = faces_[begin[half]].center[axis];
+
+    const int lower_id = int(nodes_.size());
+    nodes_.push_back(lower);
+    const int upper_id = int(nodes_.size());
+    nodes_.push_back(upper);
+    nodes_[node].child[0] = lower_id;
+    nodes_[node].child[1] = upper_id;
+
+    const size_t below = split(lower_id, tri_threshold, aabb_threshold, false) +
+                         split(upper_id, tri_threshold, aabb_threshold, false);
+    if (!is_root && below < aabb_threshold) return below;
+    nodes_[node].aabb_count = uint32_t(below);
+    return 1;
+}
+
+void Model::reserve(ResourceManager &mngr)
+{
+    reserve_node(0, mngr);
+}
+
+void Model::reserve_node(int node, ResourceManager &mngr)
+{
+    Node &nd = nodes_[node];
+    if (nd.child[0] >= 0) {
+        reserve_node(nd.child[0], mngr);
+        reserve_node(nd.child[1], mngr);
+        if (nd.aabb_count) {
+            mngr.reserve_groups(1);
+            mngr.reserve_aabbs(nd.aabb_count);
+        }
+        return;
+    }
+    // Leaf: one mesh group, its triangles, and one copy of every vertex it touches (model.cpp:57-66).
+    mngr.reserve_groups(1);
+    mngr.reserve_triangles(nd.count);
+    int used = 0;
+    for (uint32_t i = 0; i < nd.count; i++)
+        for (uint32_t v : faces_[order_[nd.first + i]].v)
+            if (slot_[v] < 0) slot_[v] = used++;
+    for (uint32_t i = 0; i < nd.count; i++)
+        for (uint32_t v : faces_[order_[nd.first + i]].v) slot_[v] = -1;
+    if (used >= (1 << 10)) throw std::length_error("leaf touches more than 1023 vertices");
+    nd.vtx_count = uint32_t(used);
+    mngr.reserve_vertices(nd.vtx_count);
+}
+
+void Model::fill(ResourceManager &mngr, uint32_t material_id)
+{
+    group_id_ = fill_node(0, mngr, material_id, nullptr);
+}
+
+// Emits the subtree in depth-first order: a box group takes its table slot and its box range before
+// its children, a leaf takes slot, vertex range and triangle range when reached (model.cpp:76-136).
+// aabb_cursor points at the next free box of the enclosing group, or is null at the model root.
+uint32_t Model::fill_node(int node, ResourceManager &mngr, uint32_t material_id, uint32_t *aabb_cursor)
+{
+    const Node nd = nodes_[node];
+    uint32_t id = 0;
+    Bounds box;
+
+    if (nd.child[0] >= 0 && nd.aabb_count) {
+        const uint32_t slot = mngr.get_groups(1);
+        const uint32_t first_box = mngr.get_aabbs(nd.aabb_count);
+        rt_group *grp = mngr.group(slot);
+        grp->aabb.aabb_offs = first_box;
+        grp->aabb.aabb_count = nd.aabb_count;
+        grp->aabb.flags = 0;
+        uint32_t cursor = first_box;
+        fill_node(nd.child[0], mngr, material_id, &cursor);
+        fill_node(nd.child[1], mngr, material_id, &cursor);
+        assert(cursor == first_box + nd.aabb_count);
+        box.add(nodes_[nd.child[0]].box);
+        box.add(nodes_[nd.child[1]].box);
+        nodes_[node].box = box;
+        id = make_group_id(slot, RT_TR_ORTHO, RT_SH_AABB);
+    } else if (nd.child[0] >= 0) {
+        // Too few leaves for a group of its own: the leaves join the enclosing group's box list.
+        fill_node(nd.child[0], mngr, material_id, aabb_cursor);
+        fill_node(nd.child[1], mngr, material_id, aabb_cursor);
+        box.add(nodes_[nd.child[0]].box);
+        box.add(nodes_[nd.child[1]].box);
+        nodes_[node].box = box;
+        return 0;
+    } else {
+        const uint32_t slot = mngr.get_groups(1);
+        rt_group *grp = mngr.group(slot);
+        grp->mesh.vtx_offs = mngr.get_vertices(nd.vtx_count);
+        grp->mesh.tri_offs = mngr.get_triangles(nd.count);
+        grp->mesh.tri_count = nd.count;
+        grp->mesh.material_id = material_id;
+        rt_vertex *vtx_out = nd.vtx_count ? mngr.vertex(grp->mesh.vtx_offs) : nullptr;
+        uint32_t *tri_out = mngr.triangle(grp->mesh.tri_offs);
+        int used = 0;
+        for (uint32_t i = 0; i < nd.count; i++) {
+            uint32_t packed = 0;
+            int shift = 0;
+            for (uint32_t v : faces_[order_[nd.first + i]].v) {
+                if (slot_[v] < 0) {
+                    slot_[v] = used++;
+                    store3(vtx_out[slot_[v]].pos, pos_[v]);
+                    store3(vtx_out[slot_[v]].norm, norm_[v]);
+                    box.add(pos_[v]);
+                }
+                packed |= uint32_t(slot_[v]) << shift;
+                shift += 10;
+            }
+            tri_out[i] = packed;
+        }
+        for (uint32_t i = 0; i < nd.count; i++)
+            for (uint32_t v : faces_[order_[nd.first + i]].v) slot_[v] = -1;
+        assert(uint32_t(used) == nd.vtx_count);
+        nodes_[node].box = box;
+        id = make_group_id(slot, RT_TR_ORTHO, RT_SH_MESH);
+    }
+
+    if (aabb_cursor) {
+        rt_aabb *out = mngr.aabb((*aabb_cursor)++);
+        store3(out->min, box.lo);
+        store3(out->max, box.hi);
+        out->group_id = id;
+        out->local_id = 0;
+    }
+    return id;
+}
+
+void Model::put(rt_aabb &aabb, const rt_matrix &mat, uint32_t local_id) const
+{
+    assert(group_id_);
+    Bounds box;
+    for (const Vec3 &p : pos_) box.add(transform_point(mat, p));
+    store3(aabb.min, box.lo);
+    store3(aabb.max, box.hi);
+    aabb.group_id = group_id_;
+    aabb.local_id = local_id;
+}
+
+}  // namespace rt
