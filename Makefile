@@ -17,8 +17,8 @@ HIP_HEADERS := $(wildcard $(CSRC)/*.h) include/rt_hip.h
 HOST_LIB_SOURCES := $(HOST)/model.cpp $(HOST)/scene.cpp $(HOST)/host_capi.cpp
 HOST_HEADERS := $(wildcard $(HOST)/*.h) include/rt_hip.h
 
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -ffp-contract=off -fno-fast-math \
-            -fgpu-rdc=0 -Wall -Wno-unused-function -Iinclude -I$(CSRC)
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -ffp-contract=off -fno-fast-math -munsafe-fp-atomics \
+            -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -I$(HOST)
 
 all: device host oracle

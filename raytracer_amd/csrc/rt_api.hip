@@ -1,0 +1,660 @@
+// rt_api.hip -- the C ABI of include/rt_hip.h: context, buffers, launch sequence, readbacks.
+//
+// Host-side successor of the reference's OpenCL plumbing (cl-helper.h; main.cpp:87-127, 219-265,
+// 345-477).  One context = one GPU = one stream.  No OpenCL, no run-time compilation: the kernels are
+// gfx950 code objects inside this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_launch.h"
+
+using namespace rtd;
+
+struct rt_ctx {
+    rt_config cfg{};
+    hipStream_t stream = nullptr;
+    uint32_t pool = 0, area_size = 0, group_count = 0;
+    bool scene_ready = false, frame_ready = false;
+
+    DevGlobal *glob = nullptr;
+    float4 *area = nullptr;
+    RaySlot *rays = nullptr;
+    rt_index_pair *index = nullptr, *next = nullptr, *sorted = nullptr;
+    rt_hit_record *hits = nullptr;
+    rt_group_data *grp_data = nullptr;
+    uchar4 *rgba = nullptr;
+    SortWorkspace ws{};
+
+    rt_group *grp = nullptr;
+    rt_matrix *mat = nullptr;
+    rt_aabb *aabb = nullptr;
+    rt_vertex *vtx = nullptr;
+    uint32_t *tri = nullptr;
+    TriRecord *tri_rec = nullptr;
+    rt_camera cam{};
+
+    uint64_t steps = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> pending;  // 5 events per timed step
+    std::vector<hipEvent_t> spare;
+    double stage_ms[RT_STAGE_COUNT] = {0, 0, 0, 0};
+    uint64_t timed_steps = 0;
+
+    std::string last_error;
+};
+
+namespace {
+
+int fail(rt_ctx *ctx, int status, const char *fmt, ...)
+{
+    char text[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(text, sizeof(text), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = text;
+    return status;
+}
+
+#define RT_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t err_ = (call);                                                                           \
+        if (err_ != hipSuccess)                                                                             \
+            return fail(ctx, err_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "%s: %s", #call, \
+                        hipGetErrorString(err_));                                                           \
+    } while (0)
+
+template <typename T>
+hipError_t dev_alloc(T *&ptr, size_t count)
+{
+    return hipMalloc(reinterpret_cast<void **>(&ptr), (count ? count : 1) * sizeof(T));
+}
+
+template <typename T>
+void dev_free(T *&ptr)
+{
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+}
+
+LaunchCtx launch_ctx(const rt_ctx *c)
+{
+    LaunchCtx l{};
+    l.stream = c->stream;
+    l.scene = Scene{c->grp, c->mat, c->aabb, c->vtx, c->tri, c->tri_rec};
+    l.frame = Frame{c->glob, c->area, c->rays, c->index, c->next, c->hits};
+    l.cam = c->cam;
+    l.grp_data = c->grp_data;
+    l.pool = c->pool;
+    l.area_size = c->area_size;
+    l.group_count = c->group_count;
+    return l;
+}
+
+int check_launch(rt_ctx *ctx, const char *what)
+{
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(ctx, RT_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(err));
+    return RT_OK;
+}
+
+void free_scene(rt_ctx *c)
+{
+    dev_free(c->grp);
+    dev_free(c->mat);
+    dev_free(c->aabb);
+    dev_free(c->vtx);
+    dev_free(c->tri);
+    dev_free(c->tri_rec);
+    dev_free(c->grp_data);
+    c->scene_ready = c->frame_ready = false;
+}
+
+// Expands one leaf's packed triangles into TriRecords with the float operations mesh_shader performs
+// per triangle (shader.cl:126-127), so the kernel's results do not depend on where they are done.
+void expand_leaf(const rt_mesh_shader &mesh, const rt_vertex *vtx, const uint32_t *tri, TriRecord *out)
+{
+    for (uint32_t i = 0; i < mesh.tri_count; i++) {
+        const uint32_t word = tri[mesh.tri_offs + i];
+        const float *a = vtx[mesh.vtx_offs + (word & 0x3FF)].pos;
+        const float *b = vtx[mesh.vtx_offs + ((word >> 10) & 0x3FF)].pos;
+        const float *c = vtx[mesh.vtx_offs + ((word >> 20) & 0x3FF)].pos;
+        TriRecord &r = out[mesh.tri_offs + i];
+        for (int k = 0; k < 3; k++) {
+            r.r0[k] = a[k];
+            r.p[k] = b[k] - a[k];
+            r.q[k] = c[k] - a[k];
+        }
+        r.n[0] = r.p[1] * r.q[2] - r.p[2] * r.q[1];
+        r.n[1] = r.p[2] * r.q[0] - r.p[0] * r.q[2];
+        r.n[2] = r.p[0] * r.q[1] - r.p[1] * r.q[0];
+    }
+}
+
+hipError_t set_global_field(rt_ctx *c, size_t offset, const void *src, size_t size)
+{
+    return hipMemcpyAsync(reinterpret_cast<char *>(c->glob) + offset, src, size, hipMemcpyHostToDevice, c->stream);
+}
+
+int resolve_timers(rt_ctx *c)
+{
+    if (c->pending.empty()) return RT_OK;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i + 4 < c->pending.size(); i += 5) {
+        for (int s = 0; s < RT_STAGE_COUNT; s++) {
+            float ms = 0;
+            RT_HIP(c, hipEventElapsedTime(&ms, c->pending[i + s], c->pending[i + s + 1]));
+            c->stage_ms[s] += ms;
+        }
+        c->timed_steps++;
+    }
+    c->spare.insert(c->spare.end(), c->pending.begin(), c->pending.end());
+    c->pending.clear();
+    return RT_OK;
+}
+
+int mark(rt_ctx *c)
+{
+    hipEvent_t ev;
+    if (!c->spare.empty()) {
+        ev = c->spare.back();
+        c->spare.pop_back();
+    } else {
+        RT_HIP(c, hipEventCreate(&ev));
+    }
+    c->pending.push_back(ev);
+    RT_HIP(c, hipEventRecord(ev, c->stream));
+    return RT_OK;
+}
+
+// One make_step (main.cpp:439-477): process, sort by group, re-pack.  The step starts and ends with
+// the live index in c->index, so the launch sequence is the same every step.
+int one_step(rt_ctx *c, bool run_process)
+{
+    const LaunchCtx l = launch_ctx(c);
+    int rc;
+    if (c->profiling && (rc = mark(c))) return rc;
+    if (run_process) launch_process_traverse(l);
+    if (c->profiling && (rc = mark(c))) return rc;
+    if (run_process) launch_process_misc(l);
+    if (c->profiling && (rc = mark(c))) return rc;
+    launch_sort(c->stream, c->ws, run_process ? c->next : c->index, c->sorted, c->pool, &c->glob->g.ray_count, c->group_count);
+    if (c->profiling && (rc = mark(c))) return rc;
+    launch_compact(l, c->sorted, c->index);
+    if (c->profiling && (rc = mark(c))) return rc;
+    if (c->profiling && c->pending.size() >= 5 * 2048 && (rc = resolve_timers(c))) return rc;
+    return check_launch(c, "make_step");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_status_string(int status)
+{
+    switch (status) {
+    case RT_OK: return "RT_OK";
+    case RT_ERR_INVALID_VALUE: return "RT_ERR_INVALID_VALUE";
+    case RT_ERR_NO_DEVICE: return "RT_ERR_NO_DEVICE";
+    case RT_ERR_OUT_OF_MEMORY: return "RT_ERR_OUT_OF_MEMORY";
+    case RT_ERR_LAUNCH: return "RT_ERR_LAUNCH";
+    case RT_ERR_NOT_READY: return "RT_ERR_NOT_READY";
+    case RT_ERR_UNSUPPORTED: return "RT_ERR_UNSUPPORTED";
+    case RT_ERR_HIP: return "RT_ERR_HIP";
+    default: return "RT_ERR_UNKNOWN";
+    }
+}
+
+const char *rt_last_error(rt_ctx *ctx)
+{
+    return ctx ? ctx->last_error.c_str() : "";
+}
+
+int rt_create(const rt_config *cfg, rt_ctx **out)
+{
+    if (!cfg || !out) return RT_ERR_INVALID_VALUE;
+    *out = nullptr;
+    if (!cfg->width || !cfg->height || !cfg->ray_count || cfg->flags) return RT_ERR_INVALID_VALUE;
+    if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) return RT_ERR_INVALID_VALUE;
+    if (uint64_t(cfg->ray_count) + RT_SORT_TILE > 0x7FFFFFFFull) return RT_ERR_INVALID_VALUE;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return RT_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= n_dev) return RT_ERR_NO_DEVICE;
+
+    rt_ctx *c = new rt_ctx;
+    c->cfg = *cfg;
+    if (!c->cfg.warp_width) c->cfg.warp_width = 64;
+    c->pool = (cfg->ray_count + RT_SORT_TILE - 1) / RT_SORT_TILE * RT_SORT_TILE;
+    c->area_size = cfg->width * cfg->height;
+    *out = c;  // so that rt_last_error / rt_destroy work on a half-built context
+
+    RT_HIP(c, hipSetDevice(cfg->device));
+    RT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    RT_HIP(c, dev_alloc(c->glob, 1));
+    RT_HIP(c, dev_alloc(c->area, c->area_size));
+    RT_HIP(c, dev_alloc(c->rays, c->pool));
+    RT_HIP(c, dev_alloc(c->index, c->pool));
+    RT_HIP(c, dev_alloc(c->next, c->pool));
+    RT_HIP(c, dev_alloc(c->sorted, c->pool));
+    RT_HIP(c, dev_alloc(c->ws.tmp, c->pool));
+    RT_HIP(c, dev_alloc(c->hits, cfg->hit_capacity));
+    RT_HIP(c, dev_alloc(c->rgba, c->area_size));
+    c->ws.tiles = c->pool / RT_SORT_TILE;
+    RT_HIP(c, dev_alloc(c->ws.counts, size_t(256) * c->ws.tiles));
+    RT_HIP(c, dev_alloc(c->ws.totals, 256));
+    RT_HIP(c, hipMemsetAsync(c->glob, 0, sizeof(DevGlobal), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->rays, 0, sizeof(RaySlot) * size_t(c->pool), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->area, 0, sizeof(float4) * size_t(c->area_size), c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_destroy(rt_ctx *c)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t ev : c->pending) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : c->spare) (void)hipEventDestroy(ev);
+    free_scene(c);
+    dev_free(c->glob);
+    dev_free(c->area);
+    dev_free(c->rays);
+    dev_free(c->index);
+    dev_free(c->next);
+    dev_free(c->sorted);
+    dev_free(c->ws.tmp);
+    dev_free(c->ws.counts);
+    dev_free(c->ws.totals);
+    dev_free(c->hits);
+    dev_free(c->rgba);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, size_t n_groups, const rt_matrix *mat,
+                    size_t n_mat, const rt_aabb *aabb, size_t n_aabb, const rt_vertex *vtx, size_t n_vtx,
+                    const uint32_t *tri, size_t n_tri)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    if (!data || !grp || !aabb) return fail(c, RT_ERR_INVALID_VALUE, "null scene array");
+    if ((n_mat && !mat) || (n_vtx && !vtx) || (n_tri && !tri)) return fail(c, RT_ERR_INVALID_VALUE, "null scene array");
+    const uint32_t G = data->group_count;
+    if (uint64_t(data->cam.width) * data->cam.height != c->area_size)
+        return fail(c, RT_ERR_INVALID_VALUE, "camera %ux%u does not match the context's image", data->cam.width, data->cam.height);
+    if (G < 8 || G > RT_GROUP_ID_MASK || n_groups > G - 1)
+        return fail(c, RT_ERR_INVALID_VALUE, "group_count %u must exceed the %zu groups given (last group is the dead-ray bin)", G, n_groups);
+    if (n_groups < 3) return fail(c, RT_ERR_INVALID_VALUE, "the three predefined groups are missing");
+
+    // Shape checks: every index a kernel will follow must stay inside the arrays given.
+    auto shader_of = [](uint32_t id) { return (id >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK; };
+    std::vector<uint8_t> kind(n_groups, 0xFF);
+    std::vector<uint32_t> work;
+    auto visit = [&](uint32_t id, const char *where) -> int {
+        const uint32_t gi = id & RT_GROUP_ID_MASK, sh = shader_of(id);
+        if (gi >= n_groups) return fail(c, RT_ERR_INVALID_VALUE, "%s refers to group %u of %zu", where, gi, n_groups);
+        if (sh != RT_SH_AABB && sh != RT_SH_MESH) return fail(c, RT_ERR_INVALID_VALUE, "%s: group %u is not a box or mesh group", where, gi);
+        if (kind[gi] == 0xFF) {
+            kind[gi] = uint8_t(sh);
+            work.push_back(id);
+        } else if (kind[gi] != sh) {
+            return fail(c, RT_ERR_INVALID_VALUE, "group %u is referenced with two shader types", gi);
+        }
+        return RT_OK;
+    };
+    int rc = visit(data->cam.root_group, "camera root");
+    if (rc) return rc;
+    std::vector<TriRecord> records(n_tri);
+    std::memset(records.data(), 0, records.size() * sizeof(TriRecord));
+    while (!work.empty()) {
+        const uint32_t id = work.back();
+        work.pop_back();
+        const rt_group &g = grp[id & RT_GROUP_ID_MASK];
+        if (shader_of(id) == RT_SH_AABB) {
+            const rt_aabb_shader &s = g.aabb;
+            if (uint64_t(s.aabb_offs) + s.aabb_count > n_aabb)
+                return fail(c, RT_ERR_INVALID_VALUE, "group %u: boxes [%u, +%u) exceed %zu", id & RT_GROUP_ID_MASK, s.aabb_offs, s.aabb_count, n_aabb);
+            if (s.aabb_count > 256)
+                return fail(c, RT_ERR_UNSUPPORTED, "group %u has %u boxes; at most 256 per group are supported", id & RT_GROUP_ID_MASK, s.aabb_count);
+            for (uint32_t i = 0; i < s.aabb_count; i++) {
+                const rt_aabb &b = aabb[s.aabb_offs + i];
+                if ((rc = visit(b.group_id, "a box"))) return rc;
+                if ((s.flags & RT_F_LOCAL0) && b.local_id >= n_mat)
+                    return fail(c, RT_ERR_INVALID_VALUE, "box %u: instance %u of %zu matrices", s.aabb_offs + i, b.local_id, n_mat);
+            }
+        } else {
+            const rt_mesh_shader &s = g.mesh;
+            if (uint64_t(s.tri_offs) + s.tri_count > n_tri)
+                return fail(c, RT_ERR_INVALID_VALUE, "group %u: triangles [%u, +%u) exceed %zu", id & RT_GROUP_ID_MASK, s.tri_offs, s.tri_count, n_tri);
+            for (uint32_t i = 0; i < s.tri_count; i++) {
+                const uint32_t w = tri[s.tri_offs + i];
+                const uint32_t top = std::max(std::max(w & 0x3FF, (w >> 10) & 0x3FF), (w >> 20) & 0x3FF);
+                if (uint64_t(s.vtx_offs) + top >= n_vtx)
+                    return fail(c, RT_ERR_INVALID_VALUE, "group %u: vertex %u exceeds %zu", id & RT_GROUP_ID_MASK, s.vtx_offs + top, n_vtx);
+            }
+            const uint32_t mid = s.material_id & RT_GROUP_ID_MASK;
+            if (mid >= n_groups) return fail(c, RT_ERR_INVALID_VALUE, "group %u: material group %u of %zu", id & RT_GROUP_ID_MASK, mid, n_groups);
+            expand_leaf(s, vtx, tri, records.data());
+        }
+    }
+    if (((data->cam.root_group >> RT_GROUP_TR_SHIFT) & RT_GROUP_TR_MASK) == RT_TR_ORTHO && data->cam.root_local >= n_mat)
+        return fail(c, RT_ERR_INVALID_VALUE, "camera root instance %u of %zu matrices", data->cam.root_local, n_mat);
+
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    c->group_count = G;
+    c->cam = data->cam;
+    RT_HIP(c, dev_alloc(c->grp, G));
+    RT_HIP(c, dev_alloc(c->mat, n_mat));
+    RT_HIP(c, dev_alloc(c->aabb, n_aabb));
+    RT_HIP(c, dev_alloc(c->vtx, n_vtx));
+    RT_HIP(c, dev_alloc(c->tri, n_tri));
+    RT_HIP(c, dev_alloc(c->tri_rec, n_tri));
+    RT_HIP(c, dev_alloc(c->grp_data, G));
+    RT_HIP(c, hipMemset(c->grp, 0, sizeof(rt_group) * size_t(G)));
+    RT_HIP(c, hipMemset(c->grp_data, 0, sizeof(rt_group_data) * size_t(G)));
+    RT_HIP(c, hipMemcpy(c->grp, grp, sizeof(rt_group) * n_groups, hipMemcpyHostToDevice));
+    if (n_mat) RT_HIP(c, hipMemcpy(c->mat, mat, sizeof(rt_matrix) * n_mat, hipMemcpyHostToDevice));
+    if (n_aabb) RT_HIP(c, hipMemcpy(c->aabb, aabb, sizeof(rt_aabb) * n_aabb, hipMemcpyHostToDevice));
+    if (n_vtx) RT_HIP(c, hipMemcpy(c->vtx, vtx, sizeof(rt_vertex) * n_vtx, hipMemcpyHostToDevice));
+    if (n_tri) RT_HIP(c, hipMemcpy(c->tri, tri, sizeof(uint32_t) * n_tri, hipMemcpyHostToDevice));
+    if (n_tri) RT_HIP(c, hipMemcpy(c->tri_rec, records.data(), sizeof(TriRecord) * n_tri, hipMemcpyHostToDevice));
+
+    DevGlobal init;
+    std::memset(&init, 0, sizeof(init));
+    init.g = *data;
+    init.g.ray_count = c->pool;
+    init.g.pixel_offset = init.g.pixel_count = init.g.old_count = 0;
+    init.warp_width = c->cfg.warp_width;
+    init.sample_limit = c->cfg.sample_limit;
+    init.hit_capacity = c->cfg.hit_capacity;
+    init.row_offset = c->cfg.row_offset;
+    RT_HIP(c, hipMemcpy(c->glob, &init, sizeof(init), hipMemcpyHostToDevice));
+    c->scene_ready = true;
+    return RT_OK;
+}
+
+int rt_init_frame(rt_ctx *c)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    if (!c->scene_ready) return fail(c, RT_ERR_NOT_READY, "rt_init_frame before rt_upload_scene");
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    RT_HIP(c, hipMemsetAsync(reinterpret_cast<char *>(c->glob) + offsetof(DevGlobal, primary_spawned), 0,
+                             2 * sizeof(unsigned long long), c->stream));
+    launch_init_frame(launch_ctx(c));
+    c->steps = 0;
+    c->frame_ready = true;
+    return check_launch(c, "init_frame");
+}
+
+int rt_step(rt_ctx *c, uint32_t n_steps)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    if (!c->frame_ready) return fail(c, RT_ERR_NOT_READY, "rt_step before rt_init_frame");
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    for (uint32_t s = 0; s < n_steps; s++) {
+        const int rc = one_step(c, true);
+        if (rc) return rc;
+        c->steps++;
+    }
+    return RT_OK;
+}
+
+int rt_set_warp_width(rt_ctx *c, uint32_t warp_width)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    if (!c->scene_ready) return fail(c, RT_ERR_NOT_READY, "rt_set_warp_width before rt_upload_scene");
+    c->cfg.warp_width = warp_width ? warp_width : 64;
+    RT_HIP(c, set_global_field(c, offsetof(DevGlobal, warp_width), &c->cfg.warp_width, sizeof(uint32_t)));
+    RT_HIP(c, hipStreamSynchronize(c->stream));  // the source of the async copy is a context field
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx *c)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_resolve_rgba8(rt_ctx *c, void *dst, int dst_is_device)
+{
+    if (!c || !dst) return RT_ERR_INVALID_VALUE;
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    launch_resolve(launch_ctx(c), dst_is_device ? dst : c->rgba);
+    int rc = check_launch(c, "resolve");
+    if (rc) return rc;
+    if (!dst_is_device) RT_HIP(c, hipMemcpyAsync(dst, c->rgba, size_t(c->area_size) * 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_area(rt_ctx *c, float *dst)
+{
+    if (!c || !dst) return RT_ERR_INVALID_VALUE;
+    RT_HIP(c, hipMemcpyAsync(dst, c->area, sizeof(float4) * size_t(c->area_size), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_get_global(rt_ctx *c, rt_global_data *dst)
+{
+    if (!c || !dst) return RT_ERR_INVALID_VALUE;
+    RT_HIP(c, hipMemcpyAsync(dst, c->glob, sizeof(rt_global_data), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_current_ray(rt_ctx *c, uint32_t *pixel_offset)
+{
+    if (!c || !pixel_offset) return RT_ERR_INVALID_VALUE;
+    rt_global_data g;
+    const int rc = rt_get_global(c, &g);
+    if (rc) return rc;
+    *pixel_offset = g.pixel_offset;
+    return RT_OK;
+}
+
+int rt_get_counters(rt_ctx *c, rt_counters *dst)
+{
+    if (!c || !dst) return RT_ERR_INVALID_VALUE;
+    DevGlobal g;
+    RT_HIP(c, hipMemcpyAsync(&g, c->glob, sizeof(g), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    dst->primary_spawned = g.primary_spawned;
+    dst->shadow_spawned = g.shadow_spawned;
+    dst->steps = c->steps;
+    return RT_OK;
+}
+
+int rt_sort_pairs(rt_ctx *c, const rt_index_pair *in, rt_index_pair *out, uint32_t count, uint32_t n, uint32_t group_count,
+                  int on_device)
+{
+    if (!c || !in || !out) return RT_ERR_INVALID_VALUE;
+    if (!count || count % RT_SORT_TILE || count > c->pool) return fail(c, RT_ERR_INVALID_VALUE, "count %u must be a multiple of %u within the pool of %u", count, RT_SORT_TILE, c->pool);
+    if (n > count || !group_count || group_count > RT_GROUP_ID_MASK + 1) return fail(c, RT_ERR_INVALID_VALUE, "bad n or group_count");
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    const size_t bytes = sizeof(rt_index_pair) * size_t(count);
+    rt_index_pair *d_in = nullptr, *d_out = nullptr;
+    if (!on_device) {
+        RT_HIP(c, dev_alloc(d_in, count));
+        RT_HIP(c, dev_alloc(d_out, count));
+        RT_HIP(c, hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    RT_HIP(c, set_global_field(c, offsetof(DevGlobal, sort_count), &n, sizeof(n)));
+    launch_sort(c->stream, c->ws, on_device ? in : d_in, on_device ? out : d_out, count, &c->glob->sort_count, group_count);
+    int rc = check_launch(c, "sort");
+    if (!on_device && !rc) {
+        const hipError_t err = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (err != hipSuccess) rc = fail(c, RT_ERR_HIP, "copy back: %s", hipGetErrorString(err));
+    }
+    const hipError_t err = hipStreamSynchronize(c->stream);
+    if (err != hipSuccess && !rc) rc = fail(c, RT_ERR_HIP, "sort: %s", hipGetErrorString(err));
+    dev_free(d_in);
+    dev_free(d_out);
+    return rc;
+}
+
+int rt_compact_groups(rt_ctx *c, const rt_index_pair *sorted, rt_index_pair *out, uint32_t count, rt_group_data *grp_data,
+                      rt_global_data *global, uint32_t warp_width)
+{
+    if (!c || !sorted || !out || !grp_data || !global) return RT_ERR_INVALID_VALUE;
+    if (!count || !warp_width || !global->group_count || global->ray_count > count)
+        return fail(c, RT_ERR_INVALID_VALUE, "bad count, warp width, group_count or ray_count");
+    for (uint32_t i = 0; i < count; i++)
+        if ((sorted[i].key & RT_GROUP_ID_MASK) >= global->group_count)
+            return fail(c, RT_ERR_INVALID_VALUE, "pair %u: group %u of %u", i, sorted[i].key & RT_GROUP_ID_MASK, global->group_count);
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    const uint32_t G = global->group_count;
+    DevGlobal host;
+    std::memset(&host, 0, sizeof(host));
+    host.g = *global;
+    host.warp_width = warp_width;
+    DevGlobal *d_glob = nullptr;
+    rt_group_data *d_grp = nullptr;
+    rt_index_pair *d_in = nullptr, *d_out = nullptr;
+    int rc = RT_OK;
+    auto step = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess && !rc) rc = fail(c, RT_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+    };
+    step(dev_alloc(d_glob, 1), "alloc");
+    step(dev_alloc(d_grp, G), "alloc");
+    step(dev_alloc(d_in, count), "alloc");
+    step(dev_alloc(d_out, count), "alloc");
+    if (!rc) {
+        step(hipMemcpyAsync(d_glob, &host, sizeof(host), hipMemcpyHostToDevice, c->stream), "upload");
+        step(hipMemcpyAsync(d_grp, grp_data, sizeof(rt_group_data) * size_t(G), hipMemcpyHostToDevice, c->stream), "upload");
+        step(hipMemcpyAsync(d_in, sorted, sizeof(rt_index_pair) * size_t(count), hipMemcpyHostToDevice, c->stream), "upload");
+        step(hipMemsetAsync(d_out, 0, sizeof(rt_index_pair) * size_t(count), c->stream), "clear");
+    }
+    if (!rc) {
+        launch_compact_raw(c->stream, d_glob, d_grp, d_in, d_out, count, G);
+        rc = check_launch(c, "compact");
+    }
+    if (!rc) {
+        step(hipMemcpyAsync(&host, d_glob, sizeof(host), hipMemcpyDeviceToHost, c->stream), "download");
+        step(hipMemcpyAsync(grp_data, d_grp, sizeof(rt_group_data) * size_t(G), hipMemcpyDeviceToHost, c->stream), "download");
+        step(hipMemcpyAsync(out, d_out, sizeof(rt_index_pair) * size_t(count), hipMemcpyDeviceToHost, c->stream), "download");
+    }
+    step(hipStreamSynchronize(c->stream), "compact");
+    if (!rc) *global = host.g;
+    dev_free(d_glob);
+    dev_free(d_grp);
+    dev_free(d_in);
+    dev_free(d_out);
+    return rc;
+}
+
+int rt_dump_state(rt_ctx *c, rt_ray_queue *ray_list, rt_index_pair *ray_index, rt_group_data *grp_data)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    if (!c->scene_ready) return fail(c, RT_ERR_NOT_READY, "no scene");
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    if (ray_list) {
+        rt_ray_queue *d_out = nullptr;
+        RT_HIP(c, dev_alloc(d_out, c->pool));
+        launch_export_rays(launch_ctx(c), d_out);
+        const hipError_t err = hipMemcpyAsync(ray_list, d_out, sizeof(rt_ray_queue) * size_t(c->pool), hipMemcpyDeviceToHost, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        dev_free(d_out);
+        if (err != hipSuccess) return fail(c, RT_ERR_HIP, "dump rays: %s", hipGetErrorString(err));
+    }
+    if (ray_index) RT_HIP(c, hipMemcpyAsync(ray_index, c->index, sizeof(rt_index_pair) * size_t(c->pool), hipMemcpyDeviceToHost, c->stream));
+    if (grp_data) RT_HIP(c, hipMemcpyAsync(grp_data, c->grp_data, sizeof(rt_group_data) * size_t(c->group_count), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return check_launch(c, "dump");
+}
+
+int rt_read_hits(rt_ctx *c, rt_hit_record *dst, uint32_t first, uint32_t count)
+{
+    if (!c || !dst) return RT_ERR_INVALID_VALUE;
+    if (uint64_t(first) + count > c->cfg.hit_capacity) return fail(c, RT_ERR_INVALID_VALUE, "hits [%u, +%u) exceed capacity %u", first, count, c->cfg.hit_capacity);
+    RT_HIP(c, hipMemcpyAsync(dst, c->hits + first, sizeof(rt_hit_record) * size_t(count), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_trace_closest(rt_ctx *c, const rt_ray *rays, uint32_t n_rays, rt_hit_record *hits)
+{
+    if (!c || (n_rays && (!rays || !hits))) return RT_ERR_INVALID_VALUE;
+    if (!c->scene_ready) return fail(c, RT_ERR_NOT_READY, "rt_trace_closest before rt_upload_scene");
+    if (n_rays > c->pool) return fail(c, RT_ERR_INVALID_VALUE, "%u rays exceed the pool of %u", n_rays, c->pool);
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    c->frame_ready = false;
+
+    rt_ray *d_rays = nullptr;
+    rt_hit_record *d_hits = nullptr, *saved_hits = c->hits;
+    RT_HIP(c, dev_alloc(d_rays, n_rays));
+    RT_HIP(c, dev_alloc(d_hits, n_rays));
+    int rc = RT_OK;
+    auto step = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess && !rc) rc = fail(c, RT_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+    };
+    // sample ids 0..n-1 get a hit record, later ids are parked; granularity 1; shaders park the ray
+    const uint32_t settings[5] = {1u, n_rays ? n_rays : 1u, n_rays, c->cfg.row_offset, kModeTraceOnly};
+    step(set_global_field(c, offsetof(DevGlobal, warp_width), settings, sizeof(settings)), "settings");
+    if (n_rays) step(hipMemcpyAsync(d_rays, rays, sizeof(rt_ray) * size_t(n_rays), hipMemcpyHostToDevice, c->stream), "upload rays");
+    c->hits = d_hits;
+    if (!rc) {
+        launch_load_rays(launch_ctx(c), d_rays, n_rays);
+        rc = one_step(c, false);  // parks the unused slots
+    }
+    uint32_t live = 1;
+    for (uint32_t guard = 0; !rc && live; guard++) {
+        if (guard > 4096) {
+            rc = fail(c, RT_ERR_NOT_READY, "rays still in flight after %u steps", guard * 8);
+            break;
+        }
+        for (int s = 0; s < 8 && !rc; s++) rc = one_step(c, true);
+        if (!rc) {
+            step(hipMemcpyAsync(&live, &c->glob->g.ray_count, sizeof(live), hipMemcpyDeviceToHost, c->stream), "poll");
+            step(hipStreamSynchronize(c->stream), "poll");
+        }
+    }
+    if (!rc && n_rays) step(hipMemcpyAsync(hits, d_hits, sizeof(rt_hit_record) * size_t(n_rays), hipMemcpyDeviceToHost, c->stream), "download hits");
+    const uint32_t restore[5] = {c->cfg.warp_width, c->cfg.sample_limit, c->cfg.hit_capacity, c->cfg.row_offset, 0u};
+    step(set_global_field(c, offsetof(DevGlobal, warp_width), restore, sizeof(restore)), "restore");
+    step(hipStreamSynchronize(c->stream), "trace");
+    c->hits = saved_hits;
+    dev_free(d_rays);
+    dev_free(d_hits);
+    return rc;
+}
+
+int rt_set_profiling(rt_ctx *c, int enabled)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    const int rc = resolve_timers(c);
+    if (rc) return rc;
+    c->profiling = enabled != 0;
+    if (enabled) {
+        for (double &ms : c->stage_ms) ms = 0;
+        c->timed_steps = 0;
+    }
+    return RT_OK;
+}
+
+int rt_get_stage_times(rt_ctx *c, double ms[RT_STAGE_COUNT], uint64_t *steps)
+{
+    if (!c || !ms) return RT_ERR_INVALID_VALUE;
+    const int rc = resolve_timers(c);
+    if (rc) return rc;
+    for (int s = 0; s < RT_STAGE_COUNT; s++) ms[s] = c->stage_ms[s];
+    if (steps) *steps = c->timed_steps;
+    return RT_OK;
+}
+
+void *rt_stream(rt_ctx *c)
+{
+    return c ? static_cast<void *>(c->stream) : nullptr;
+}
+
+}  // extern "C"

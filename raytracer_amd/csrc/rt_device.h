@@ -1,0 +1,150 @@
+// rt_device.h -- device-side data layout and small math helpers shared by the gfx950 kernels.
+//
+// Floating point contract (the parity tests rely on it): the library is built with
+// -ffp-contract=off, every expression below is evaluated in float exactly as written, division and
+// sqrt are the correctly rounded ones.  dot(a,b) = (ax*bx + ay*by) + az*bz,
+// normalize(v) = v * (1 / sqrt(dot(v,v))), pow(x,5) and pow(x,100) are products of repeated squares.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_hip.h"
+
+namespace rtd {
+
+constexpr uint32_t kIdMask = RT_GROUP_ID_MASK;
+constexpr uint32_t kWave = 64;
+constexpr uint32_t kModeTraceOnly = 1u;  // shader groups park the ray instead of shading (rt_trace_closest)
+
+struct RayHit {
+    float pos;
+    uint32_t group_id;
+    uint32_t local0, local1;
+};
+
+// One ray slot, 256 bytes, 256-byte aligned: the fields every traversal step touches (meta, ray,
+// head of the queue) sit in the first 128-byte line.  Same content as the reference's RayQueue
+// (ray-tracer.h:164-170) plus the sample id and the triangle of the last committed hit.
+struct alignas(256) RaySlot {
+    uint32_t pixel, type, material_id, queue_len;  //   0
+    float4 start_min;                              //  16  (start.xyz, t_min)
+    float4 dir_max;                                //  32  (dir.xyz, t_max)
+    RayHit queue[RT_MAX_QUEUE_LEN];                //  48
+    float4 weight;                                 // 176
+    float4 norm;                                   // 192
+    RayHit orig;                                   // 208
+    RayHit root;                                   // 224
+    uint32_t sample_id, hit_tri, pad0, pad1;       // 240
+};
+static_assert(sizeof(RaySlot) == 256, "ray slot must be 256 bytes");
+
+// Triangle of a leaf, expanded when the scene is uploaded: first corner, two edges and their cross
+// product (the values mesh_shader derives per triangle, shader.cl:126-127), 48 bytes, fetched with
+// scalar loads because every lane of a wave is in the same leaf.
+struct alignas(16) TriRecord {
+    float r0[3], p[3], q[3], n[3];
+};
+static_assert(sizeof(TriRecord) == 48, "triangle record must be 48 bytes");
+
+// Device-resident frame state: the reference's GlobalData (ray-tracer.h:106-111) followed by what the
+// reference fixes at build time or does not have.
+struct alignas(16) DevGlobal {
+    rt_global_data g;
+    uint32_t warp_width, sample_limit, hit_capacity, row_offset;
+    uint32_t mode, sort_count, pad0, pad1;  // sort_count: element count for stand-alone sort calls
+    unsigned long long primary_spawned, shadow_spawned;
+};
+
+struct Scene {
+    const rt_group *grp;
+    const rt_matrix *mat;
+    const rt_aabb *aabb;
+    const rt_vertex *vtx;
+    const uint32_t *tri;
+    const TriRecord *tri_rec;
+};
+
+struct Frame {
+    DevGlobal *glob;
+    float4 *area;
+    RaySlot *rays;
+    rt_index_pair *index;        // (group key, slot) in processing order, input of a step
+    rt_index_pair *next;         // the same pairs with the keys after the step
+    rt_hit_record *hits;
+};
+
+// ---------------------------------------------------------------- vector helpers
+
+struct V3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 xyz(const float4 &v) { return V3{v.x, v.y, v.z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+
+__device__ __forceinline__ float pow5(float x)
+{
+    const float x2 = x * x;
+    return (x2 * x2) * x;
+}
+__device__ __forceinline__ float pow100(float x)
+{
+    const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32;
+    return (x64 * x32) * x4;
+}
+
+// Pointers into the constant address space: loads through them with a wave-uniform address are
+// scalar loads (s_load_dwordx4/x8), which is how node payload reaches a wave whose lanes all sit in
+// the same group.  Only used on scene arrays, which no kernel writes.
+template <typename T>
+using ConstPtr = const __attribute__((address_space(4))) T *;
+
+template <typename T>
+__device__ __forceinline__ ConstPtr<T> const_ptr(const void *p)
+{
+    return (ConstPtr<T>)(uintptr_t)p;
+}
+
+// Built-in vector types: unlike HIP's float4/uint4 structs they can be loaded through ConstPtr.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// The value of v in the first active lane, in a scalar register.  Call it where all active lanes are
+// known to hold the same v: written as an asm statement so that the optimiser can neither fold it into
+// an earlier readfirstlane nor replace it by the per-lane v it was proven equal to -- either would turn
+// the scalar loads that depend on it back into per-lane loads.
+__device__ __forceinline__ uint32_t uniform_value(uint32_t v)
+{
+    uint32_t s;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v));
+    return s;
+}
+
+// Largest v (0..127) among the ACTIVE lanes of the wave, by bisection with ballots; unlike a shuffle
+// reduction it never looks at the registers of lanes that are switched off.
+__device__ __forceinline__ uint32_t wave_max_upto127(uint32_t v)
+{
+    uint32_t best = 0;
+#pragma unroll
+    for (int bit = 6; bit >= 0; bit--) {
+        const uint32_t trial = best | (1u << bit);
+        if (__ballot(v >= trial)) best = trial;
+    }
+    return best;
+}
+
+}  // namespace rtd

@@ -1,0 +1,754 @@
+// rt_kernels.hip -- gfx950 kernels for traversal/intersection, shading/spawn, queue compaction and
+// frame set-up/resolve.
+//
+// What they compute is what the reference's `process` kernel and its helpers compute
+// (ray-tracer.cl:10-232, shader.cl:6-139) and what count_groups / update_groups / set_ray_index
+// compute (ray-tracer.cl:235-302).  How they compute it is specific to CDNA4:
+//   * rays arrive sorted by group, so a wave's lanes normally sit in ONE group; the group's payload
+//     (box list, expanded triangles) is wave-uniform and is fetched with scalar loads from the
+//     constant address space, while each lane keeps its own ray in VGPRs;
+//   * a wave that does hold several groups (unaligned tails, drain mode) peels them off one at a time
+//     (`while (todo) { g = readfirstlane(key); ... }`), so the kernels are correct for any order;
+//   * the up-to-64 candidate boxes of a visit live in LDS as [entry][thread] columns: any per-lane
+//     entry index maps lane -> bank (tid mod 32), conflict-free for 4-byte accesses;
+//   * the pending-node queue of a ray is merged straight into its slot in HBM from a register
+//     snapshot of the old entries -- no scratch memory;
+//   * box groups and everything else run as two kernels with different register/LDS budgets; both
+//     read the step's keys from `index` and write the new ones to `next`, so a ray advanced by one
+//     kernel is never picked up again by the other in the same step.
+#include "rt_device.h"
+
+namespace rtd {
+
+struct ProcessArgs {
+    Scene scene;
+    Frame frame;
+    rt_camera cam;
+    uint32_t group_count;
+};
+
+// ---------------------------------------------------------------- ray set-up (ray-tracer.cl:10-74)
+
+__device__ __forceinline__ void deinterleave(uint32_t val, uint32_t &a, uint32_t &b)
+{
+    a = val & 0x55555555u;
+    b = (val >> 1) & 0x55555555u;
+    a = (a | a >> 1) & 0x33333333u;  b = (b | b >> 1) & 0x33333333u;
+    a = (a | a >> 2) & 0x0F0F0F0Fu;  b = (b | b >> 2) & 0x0F0F0F0Fu;
+    a = (a | a >> 4) & 0x00FF00FFu;  b = (b | b >> 4) & 0x00FF00FFu;
+    a = (a | a >> 8) & 0x0000FFFFu;  b = (b | b >> 8) & 0x0000FFFFu;
+}
+
+__device__ __forceinline__ float subpixel(uint32_t val)
+{
+    val = (val % 15) + 1;
+    val = (val & 1) << 3 | (val & 2) << 1 | (val & 4) >> 1 | (val & 8) >> 3;
+    return ((float)val - 0.5f) / 15.0f;
+}
+
+// reset_ray (ray-tracer.cl:10-16)
+__device__ __forceinline__ uint32_t reset_ray(RaySlot *ray, uint32_t group_id, uint32_t local0, uint32_t local1,
+                                              uint32_t end_group)
+{
+    ray->orig.group_id = group_id;
+    ray->orig.local0 = local0;
+    ray->orig.local1 = local1;
+    ray->queue[0] = RayHit{0.001f, group_id, local0, local1};
+    ray->start_min.w = 0.001f;
+    ray->dir_max.w = INFINITY;
+    ray->queue_len = 1;
+    ray->material_id = end_group;
+    return group_id;
+}
+
+// init_ray (ray-tracer.cl:56-74).  Sample ids at or beyond the limit take the dead-ray exit the
+// reference left commented out (ray-tracer.cl:61): the slot is left alone and parked in the last group.
+__device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlobal *glob, RaySlot *ray,
+                                             rt_hit_record *hits, uint32_t group_count, uint32_t sample, bool &started)
+{
+    const uint32_t limit = glob->sample_limit;
+    started = !(limit && sample >= limit);
+    if (!started) return group_count - 1;
+    const uint32_t total = cam.width * cam.height;
+    uint32_t sx, sy;
+    deinterleave(sample / total, sx, sy);
+    const uint32_t pixel = sample % total;
+    const float x = (float)(pixel % cam.width) + subpixel(sx);
+    const float y = (float)(pixel / cam.width + glob->row_offset) + subpixel(sy);
+
+    ray->pixel = pixel;
+    ray->type = RT_RAY_PRIMARY;
+    ray->weight = make_float4(1, 1, 1, 1);
+    const V3 tl = v3(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
+    const V3 dx = v3(cam.dx[0], cam.dx[1], cam.dx[2]), dy = v3(cam.dy[0], cam.dy[1], cam.dy[2]);
+    const V3 dir = normalize((tl + dx * x) + dy * y);
+    ray->start_min.x = cam.eye[0];
+    ray->start_min.y = cam.eye[1];
+    ray->start_min.z = cam.eye[2];
+    ray->dir_max.x = dir.x;
+    ray->dir_max.y = dir.y;
+    ray->dir_max.z = dir.z;
+    ray->root = RayHit{0.0f, cam.root_group, cam.root_local, 0u};
+    ray->sample_id = sample;
+    if (sample < glob->hit_capacity) hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    return reset_ray(ray, cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
+}
+
+// One atomic per wave for a per-lane event count.
+__device__ __forceinline__ void count_lanes(unsigned long long *counter, bool flag)
+{
+    const unsigned long long mask = __ballot(flag);
+    if (flag && lane_id() == (uint32_t)(__ffsll((long long)mask) - 1)) atomicAdd(counter, (unsigned long long)__popcll(mask));
+}
+
+// ---------------------------------------------------------------- frame kernels
+
+// init_groups (ray-tracer.cl:22-26)
+__global__ void k_init_groups(rt_group_data *grp_data, uint32_t group_count)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= group_count) return;
+    grp_data[g].count[1] = 0;
+    grp_data[g].offset[1] = 0xFFFFFFFFu;
+}
+
+// init_rays (ray-tracer.cl:76-82)
+__global__ void k_init_rays(ProcessArgs a, uint32_t pool)
+{
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= pool) return;
+    bool started;
+    const uint32_t key = init_ray(a.cam, a.frame.glob, &a.frame.rays[index], a.frame.hits, a.group_count, index, started);
+    a.frame.index[index] = rt_index_pair{key, index};
+    count_lanes(&a.frame.glob->primary_spawned, started);
+    if (index) return;
+    a.frame.glob->g.pixel_offset = pool;
+    a.frame.glob->g.pixel_count = 0;
+    a.frame.glob->g.ray_count = pool;
+}
+
+// Loads caller rays as samples 0..n_rays-1 (rt_trace_closest); the remaining slots are parked.
+__global__ void k_load_rays(ProcessArgs a, uint32_t pool, const rt_ray *rays, uint32_t n_rays)
+{
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= pool) return;
+    uint32_t key = a.group_count - 1;
+    if (index < n_rays) {
+        bool started;
+        RaySlot *ray = &a.frame.rays[index];
+        key = init_ray(a.cam, a.frame.glob, ray, a.frame.hits, a.group_count, index, started);
+        const rt_ray r = rays[index];
+        ray->start_min = make_float4(r.start_min[0], r.start_min[1], r.start_min[2], r.start_min[3]);
+        ray->dir_max = make_float4(r.dir_max[0], r.dir_max[1], r.dir_max[2], r.dir_max[3]);
+        ray->queue[0].pos = r.start_min[3];
+    }
+    a.frame.index[index] = rt_index_pair{key, index};
+    if (index) return;
+    a.frame.glob->g.pixel_offset = pool;
+    a.frame.glob->g.pixel_count = 0;
+    a.frame.glob->g.ray_count = pool;
+}
+
+// update_image (ray-tracer.cl:305-309), writing RGBA8 the way write_imagef converts to UNORM8.
+__global__ void k_resolve_rgba8(const float4 *area, uchar4 *out, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4 c = area[i];
+    const float denom = c.w + 1e-6f;
+    const float e = 1 / 2.2f;
+    float v[4] = {powf(c.x / denom, e), powf(c.y / denom, e), powf(c.z / denom, e), powf(c.w / denom, e)};
+    unsigned char b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float x = v[k];
+        x = x != x ? 0.0f : fminf(fmaxf(x, 0.0f), 1.0f);
+        b[k] = (unsigned char)__float2int_rn(x * 255.0f);
+    }
+    out[i] = make_uchar4(b[0], b[1], b[2], b[3]);
+}
+
+// ---------------------------------------------------------------- transform (shader.cl:43-73)
+
+struct LocalRay {
+    V3 start, dir;
+    float tmin, tmax;
+    V3 m0, m1, m2;  // columns of the instance rotation (identity for world-space groups)
+};
+
+__device__ __forceinline__ LocalRay make_local(uint32_t g, const RaySlot *ray, uint32_t local0, const rt_matrix *mat_list)
+{
+    LocalRay r;
+    const float4 sm = ray->start_min, dm = ray->dir_max;
+    r.start = xyz(sm);
+    r.dir = xyz(dm);
+    r.tmin = sm.w;
+    r.tmax = dm.w;
+    r.m0 = v3(1, 0, 0);
+    r.m1 = v3(0, 1, 0);
+    r.m2 = v3(0, 0, 1);
+    if (((g >> RT_GROUP_TR_SHIFT) & RT_GROUP_TR_MASK) == RT_TR_ORTHO) {
+        const float4 *m = reinterpret_cast<const float4 *>(&mat_list[local0]);
+        const float4 mx = m[0], my = m[1], mz = m[2];
+        r.m0 = v3(mx.x, my.x, mz.x);
+        r.m1 = v3(mx.y, my.y, mz.y);
+        r.m2 = v3(mx.z, my.z, mz.z);
+        const V3 rel = r.start - v3(mx.w, my.w, mz.w);
+        const V3 vx = xyz(mx), vy = xyz(my), vz = xyz(mz);
+        r.start = (vx * rel.x + vy * rel.y) + vz * rel.z;
+        const V3 d = r.dir;
+        r.dir = (vx * d.x + vy * d.y) + vz * d.z;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------- queue helpers
+
+// Snapshot of the pending entries queue[1..queue_len) in registers (static indices only).
+struct OldQueue {
+    RayHit e[RT_MAX_QUEUE_LEN];
+};
+
+__device__ __forceinline__ void load_pending(OldQueue &old, const RaySlot *ray, uint32_t queue_len)
+{
+#pragma unroll
+    for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
+        old.e[i] = RayHit{0.0f, 0u, 0u, 0u};
+        if ((uint32_t)i < queue_len) old.e[i] = ray->queue[i];
+    }
+}
+
+// save_queue + copy_queue for a queue that is either the shifted old one or empty
+// (ray-tracer.cl:154-168 and 184-203).  Returns the new sort key.
+__device__ __forceinline__ uint32_t store_shifted(RaySlot *ray, const OldQueue &old, uint32_t len, float head_pos,
+                                                  uint32_t end_group)
+{
+#pragma unroll
+    for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
+        if ((uint32_t)i < len) ray->queue[i] = old.e[i + 1];
+    if (len) {
+        ray->queue_len = len;
+        ray->start_min.w = head_pos;
+        return old.e[1].group_id;
+    }
+    // Empty: the head becomes the ray's end group.  queue[0].pos keeps its value (the reference leaves
+    // it indeterminate, ray-tracer.cl:164,201), queue_len and t_min are left alone.
+    ray->queue[0].group_id = end_group;
+    ray->queue[0].local0 = 0;
+    ray->queue[0].local1 = 0;
+    return end_group;
+}
+
+// ---------------------------------------------------------------- shaders (shader.cl:6-40)
+
+__device__ __forceinline__ void area_add(float4 *area, uint32_t pixel, float r, float g, float b, float w)
+{
+    float *px = reinterpret_cast<float *>(&area[pixel]);
+    unsafeAtomicAdd(px + 0, r);
+    unsafeAtomicAdd(px + 1, g);
+    unsafeAtomicAdd(px + 2, b);
+    unsafeAtomicAdd(px + 3, w);
+}
+
+__device__ __forceinline__ uint32_t sky_or_light_shader(const ProcessArgs &a, RaySlot *ray, bool is_light)
+{
+    const float4 w = ray->weight;
+    const float cr = is_light ? 1.0f : 0.5f;
+    area_add(a.frame.area, ray->pixel, w.x * cr, w.y * 1.0f, w.z * 1.0f, w.w * 1.0f);
+    ray->queue[0].group_id = RT_SPAWN_GROUP;
+    return RT_SPAWN_GROUP;
+}
+
+__device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color)
+{
+    const float l = 0.57735026f;
+    const V3 light = v3(l, -l, l);
+    const float alpha = 100, f0 = 0.04f;
+    const float4 sm = ray->start_min, dm = ray->dir_max;
+    const V3 dir = xyz(dm), norm = normalize(xyz(ray->norm));
+    const V3 hvec = normalize(light - dir);
+    float spec = (alpha + 2) / 8 * pow100(fmaxf(0.0f, dot(norm, hvec)));
+    spec *= f0 + (1 - f0) * pow5(fmaxf(0.0f, -dot(dir, hvec)));
+    const float lambert = fmaxf(0.0f, dot(light, norm));
+    const float sw = spec * color.w;
+    const V3 c = v3(color.x + sw, color.y + sw, color.z + sw) * lambert;
+
+    float4 w = ray->weight;
+    w.x *= c.x;
+    w.y *= c.y;
+    w.z *= c.z;
+    w.w *= 1.0f;
+    ray->weight = w;
+    ray->type = RT_RAY_SHADOW;
+    const V3 s = xyz(sm) + dir * dm.w;
+    ray->start_min.x = s.x;
+    ray->start_min.y = s.y;
+    ray->start_min.z = s.z;
+    ray->dir_max.x = light.x;
+    ray->dir_max.y = light.y;
+    ray->dir_max.z = light.z;
+    const RayHit root = ray->root;
+    return reset_ray(ray, root.group_id, root.local0, root.local1, RT_LIGHT_GROUP);
+}
+
+// ---------------------------------------------------------------- leaf visit (shader.cl:115-139, ray-tracer.cl:149-203)
+
+__device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const ProcessArgs &a)
+{
+    const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // vtx_offs, tri_offs, tri_count, material_id
+    const uint32_t queue_len = ray->queue_len;
+    const RayHit head = ray->queue[0];
+    const LocalRay lr = make_local(g, ray, head.local0, a.scene.mat);
+
+    ConstPtr<f32x4> rec = const_ptr<f32x4>(a.scene.tri_rec + grp.y);  // three 16-byte words per triangle
+    float best = lr.tmax, hit_u = 0, hit_v = 0;
+    uint32_t hit_index = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < grp.z; i++) {
+        const f32x4 w0 = rec[3 * i], w1 = rec[3 * i + 1], w2 = rec[3 * i + 2];  // r0.xyz p.x | p.yz q.xy | q.z n.xyz
+        const V3 p = v3(w0.w, w1.x, w1.y), q = v3(w1.z, w1.w, w2.x), n = v3(w2.y, w2.z, w2.w);
+        const V3 r = v3(w0.x, w0.y, w0.z) - lr.start;
+        float w = dot(lr.dir, n);
+        w = 1 / w;
+        const float tt = dot(r, n) * w;
+        if (!(tt > lr.tmin && tt < best)) continue;
+        const V3 dr = cross(lr.dir, r);
+        const float u = -dot(q, dr) * w, v = dot(p, dr) * w;
+        if (!(u >= 0 && v >= 0 && u + v <= 1)) continue;
+        best = tt;
+        hit_u = u;
+        hit_v = v;
+        hit_index = i;
+    }
+
+    OldQueue old;
+    load_pending(old, ray, queue_len);
+    uint32_t len = queue_len - 1;
+    if (hit_index == 0xFFFFFFFFu)  // miss: pop the head (ray-tracer.cl:154-165)
+        return store_shifted(ray, old, len, head.pos, ray->material_id);
+
+    // insert_stop (ray-tracer.cl:173-203)
+    uint32_t end_group;
+    if (ray->type == RT_RAY_SHADOW) {
+        unsafeAtomicAdd(reinterpret_cast<float *>(&a.frame.area[ray->pixel]) + 3, ray->weight.w);
+        end_group = RT_SPAWN_GROUP;
+    } else {
+        const uint32_t word = a.scene.tri[grp.y + hit_index];
+        const rt_vertex *vtx = a.scene.vtx + grp.x;
+        const float4 n0 = *reinterpret_cast<const float4 *>(vtx[word & 0x3FF].norm);
+        const float4 n1 = *reinterpret_cast<const float4 *>(vtx[(word >> 10) & 0x3FF].norm);
+        const float4 n2 = *reinterpret_cast<const float4 *>(vtx[(word >> 20) & 0x3FF].norm);
+        const V3 nn = (xyz(n0) * (1 - hit_u - hit_v) + xyz(n1) * hit_u) + xyz(n2) * hit_v;
+        const V3 nw = (lr.m0 * nn.x + lr.m1 * nn.y) + lr.m2 * nn.z;
+        ray->norm = make_float4(nw.x, nw.y, nw.z, 0.0f);
+        ray->dir_max.w = best;
+        ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
+        ray->hit_tri = hit_index;
+        const uint32_t sid = ray->sample_id;
+        if (sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
+        end_group = grp.w;
+    }
+    // pending nodes that start at or beyond the hit are dropped, and everything after them
+#pragma unroll
+    for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
+        if ((uint32_t)i < len && old.e[i + 1].pos >= best) len = i;
+    ray->material_id = end_group;
+    return store_shifted(ray, old, len, head.pos, end_group);
+}
+
+// ---------------------------------------------------------------- process, everything but box groups
+
+__global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t pool)
+{
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    const DevGlobal *glob = a.frame.glob;
+    if (index >= pool) return;
+    const rt_index_pair entry = a.frame.index[index];
+    if (index >= glob->g.ray_count) {  // parked entry: not processed, carried over
+        a.frame.next[index] = entry;
+        return;
+    }
+    const uint32_t key = entry.key;
+    RaySlot *ray = &a.frame.rays[entry.slot];
+    const uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
+    if (shader == RT_SH_AABB) return;
+    const uint32_t dead = a.group_count - 1;
+    const bool trace_only = (glob->mode & kModeTraceOnly) != 0;
+
+    uint32_t new_key = key;
+    bool todo = true;
+    while (todo) {
+        if (key != __builtin_amdgcn_readfirstlane(key)) continue;
+        todo = false;
+        const uint32_t g = uniform_value(key);  // every lane still here holds the same key
+        switch ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) {
+        case RT_SH_SPAWN: {
+            bool started;
+            new_key = init_ray(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
+            count_lanes(&a.frame.glob->primary_spawned, started);
+            break;
+        }
+        case RT_SH_SKY:
+        case RT_SH_LIGHT:
+            if (trace_only) {
+                ray->queue[0].group_id = new_key = dead;
+                break;
+            }
+            new_key = sky_or_light_shader(a, ray, ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_LIGHT);
+            break;
+        case RT_SH_MATERIAL: {
+            if (trace_only) {
+                ray->queue[0].group_id = new_key = dead;
+                break;
+            }
+            const f32x4 color = *const_ptr<f32x4>(a.scene.grp + (g & kIdMask));
+            new_key = mat_shader(ray, make_float4(color.x, color.y, color.z, color.w));
+            count_lanes(&a.frame.glob->shadow_spawned, true);
+            break;
+        }
+        case RT_SH_MESH:
+            new_key = visit_mesh(g, ray, a);
+            break;
+        default: {  // unknown shader type: the reference falls through to the pop (ray-tracer.cl:152-165)
+            const uint32_t queue_len = ray->queue_len;
+            const float head_pos = ray->queue[0].pos;
+            OldQueue old;
+            load_pending(old, ray, queue_len);
+            new_key = store_shifted(ray, old, queue_len - 1, head_pos, ray->material_id);
+            break;
+        }
+        }
+    }
+    a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
+}
+
+// ---------------------------------------------------------------- process, box groups
+// aabb_shader (shader.cl:76-101) + insert_hits (ray-tracer.cl:90-117, 205-231)
+
+constexpr int kAabbThreads = 256;
+
+__global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a)
+{
+    // Candidate boxes of each lane's visit: entry position and index of the box in the group's list.
+    __shared__ float s_pos[RT_MAX_HITS][kAabbThreads];
+    __shared__ uint8_t s_idx[RT_MAX_HITS][kAabbThreads];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t index = blockIdx.x * blockDim.x + tid;
+    const DevGlobal *glob = a.frame.glob;
+    if (index >= glob->g.ray_count) return;
+    const rt_index_pair entry = a.frame.index[index];
+    const uint32_t key = entry.key;
+    if (((key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) != RT_SH_AABB) return;
+    RaySlot *ray = &a.frame.rays[entry.slot];
+
+    uint32_t new_key = key;
+    bool todo = true;
+    while (todo) {
+        if (key != __builtin_amdgcn_readfirstlane(key)) continue;
+        todo = false;
+        const uint32_t g = uniform_value(key);  // every lane still here holds the same key
+
+        const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
+        const uint32_t old_len = ray->queue_len;
+        const RayHit head = ray->queue[0];
+        const LocalRay lr = make_local(g, ray, head.local0, a.scene.mat);
+        const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
+
+        ConstPtr<f32x8> box = const_ptr<f32x8>(a.scene.aabb + grp.x);  // min.xyz, group id, max.xyz, local id
+        uint32_t n = 0;
+        bool too_many = false;
+        for (uint32_t i = 0; i < grp.y; i++) {
+            const f32x8 b = box[i];
+            const V3 pos1 = (v3(b.s0, b.s1, b.s2) - lr.start) * inv_dir;
+            const V3 pos2 = (v3(b.s4, b.s5, b.s6) - lr.start) * inv_dir;
+            const float t_min = fmaxf(fmaxf(fminf(pos1.x, pos2.x), fminf(pos1.y, pos2.y)), fminf(pos1.z, pos2.z));
+            const float t_max = fminf(fminf(fmaxf(pos1.x, pos2.x), fmaxf(pos1.y, pos2.y)), fmaxf(pos1.z, pos2.z));
+            if (!(t_max > t_min && t_max > lr.tmin && t_min < lr.tmax)) continue;
+            if (too_many) continue;
+            if (n >= RT_MAX_HITS) {  // the reference gives up on the whole node (shader.cl:93)
+                too_many = true;
+                continue;
+            }
+            s_pos[n][tid] = fmaxf(t_min, lr.tmin);
+            s_idx[n][tid] = (uint8_t)i;
+            n++;
+        }
+        if (too_many) n = 0;
+
+        // sort_hits (ray-tracer.cl:90-117): the reference's compare-exchange network, run with
+        // wave-uniform (i, j) so every LDS access has a uniform row; lanes with fewer entries idle.
+        const uint32_t n_max = wave_max_upto127(n);
+        for (uint32_t base = 1; base < n_max; base *= 2) {
+            for (uint32_t i = base; i < n_max; i++) {
+                if (!(i & base)) continue;
+                const uint32_t j = i - 2 * (i & (base - 1)) - 1;
+                if (i < n) {
+                    const float pj = s_pos[j][tid], pi = s_pos[i][tid];
+                    if (pj > pi) {
+                        const uint8_t ij = s_idx[j][tid], ii = s_idx[i][tid];
+                        s_pos[j][tid] = pi;  s_pos[i][tid] = pj;
+                        s_idx[j][tid] = ii;  s_idx[i][tid] = ij;
+                    }
+                }
+            }
+            for (uint32_t offs = base / 2; offs; offs /= 2)
+                for (uint32_t i = offs; i < n_max; i++) {
+                    if (!(i & offs)) continue;
+                    const uint32_t j = i - offs;
+                    if (i < n) {
+                        const float pj = s_pos[j][tid], pi = s_pos[i][tid];
+                        if (pj > pi) {
+                            const uint8_t ij = s_idx[j][tid], ii = s_idx[i][tid];
+                            s_pos[j][tid] = pi;  s_pos[i][tid] = pj;
+                            s_idx[j][tid] = ii;  s_idx[i][tid] = ij;
+                        }
+                    }
+                }
+        }
+
+        // insert_hits (ray-tracer.cl:205-231): merge the sorted candidates with the pending entries,
+        // old entry first on equal position, at most 8 entries, the 8th turned into a root restart.
+        OldQueue old;
+        load_pending(old, ray, old_len);
+        const bool take0 = (grp.z & RT_F_LOCAL0) != 0, take1 = (grp.z & RT_F_LOCAL1) != 0;
+        const rt_aabb *list = a.scene.aabb + grp.x;
+        uint32_t k = 0, next = 0, first_group = 0;
+        bool overflow = false;
+
+        auto emit_candidate = [&]() {
+            const uint32_t bi = s_idx[next][tid];
+            const uint32_t child = list[bi].group_id, child_local = list[bi].local_id;
+            ray->queue[k] = RayHit{s_pos[next][tid], child, take0 ? child_local : head.local0, take1 ? child_local : head.local1};
+            if (k == 0) first_group = child;
+            k++;
+            next++;
+            if (k == RT_MAX_QUEUE_LEN) overflow = true;
+        };
+
+#pragma unroll
+        for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
+            if ((uint32_t)i < old_len && !overflow) {
+                const float pos = old.e[i].pos;
+                while (!overflow && next < n && s_pos[next][tid] < pos) emit_candidate();
+                if (!overflow) {
+                    ray->queue[k] = old.e[i];
+                    if (k == 0) first_group = old.e[i].group_id;
+                    k++;
+                    if (k == RT_MAX_QUEUE_LEN) overflow = true;
+                }
+            }
+        }
+        while (!overflow && next < n) emit_candidate();
+        if (overflow) {  // ray-tracer.cl:228-231: keep the position, restart from the root later
+            const RayHit root = ray->root;
+            ray->queue[RT_MAX_QUEUE_LEN - 1].group_id = root.group_id;
+            ray->queue[RT_MAX_QUEUE_LEN - 1].local0 = root.local0;
+            ray->queue[RT_MAX_QUEUE_LEN - 1].local1 = root.local1;
+        }
+        // save_queue (ray-tracer.cl:157-165)
+        if (k) {
+            ray->queue_len = k;
+            ray->start_min.w = head.pos;
+            new_key = first_group;
+        } else {
+            const uint32_t end_group = ray->material_id;
+            ray->queue[0].group_id = end_group;
+            ray->queue[0].local0 = 0;
+            ray->queue[0].local1 = 0;
+            new_key = end_group;
+        }
+    }
+    a.frame.next[index] = rt_index_pair{new_key, entry.slot};
+}
+
+// ---------------------------------------------------------------- queue compaction (ray-tracer.cl:235-302)
+
+// count_groups (ray-tracer.cl:235-253): count.s0[g] = number of sorted entries whose group id is <= g,
+// here found by one binary search per group instead of one boundary test per ray.
+__global__ void k_count_groups(const DevGlobal *glob, rt_group_data *grp_data, const rt_index_pair *sorted)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= glob->g.group_count) return;
+    uint32_t lo = 0, hi = glob->g.ray_count;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((sorted[mid].key & kIdMask) <= g) lo = mid + 1;
+        else hi = mid;
+    }
+    grp_data[g].count[0] = lo;
+}
+
+constexpr int kScanThreads = 1024;
+
+// update_groups (ray-tracer.cl:255-291) as one work-group: each thread owns a contiguous run of
+// groups, the runs are chained by a block-wide exclusive scan of (aligned, parked) counts.
+__global__ __launch_bounds__(kScanThreads) void k_update_groups(DevGlobal *glob, rt_group_data *grp_data)
+{
+    __shared__ uint2 s_wave[kScanThreads / 64];
+    __shared__ uint2 s_total;
+    const uint32_t n = glob->g.group_count, warp = glob->warp_width;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + kScanThreads - 1) / kScanThreads;
+    const uint32_t first = tid * per, last = first + per < n ? first + per : n;
+
+    // pass 1: this thread's totals
+    uint2 mine = make_uint2(0, 0);
+    for (uint32_t pos = first; pos < last; pos++) {
+        const uint32_t start = pos ? grp_data[pos - 1].count[0] : 0;
+        uint32_t tot = grp_data[pos].count[0] - start + grp_data[pos].count[1];
+        uint32_t tail = tot;
+        if (pos != n - 1) tail %= warp;
+        mine.x += tot - tail;
+        mine.y += tail;
+    }
+    // block-wide exclusive scan of `mine`
+    uint2 incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t ox = (uint32_t)__shfl_up((int)incl.x, off, 64), oy = (uint32_t)__shfl_up((int)incl.y, off, 64);
+        if ((tid & 63) >= (uint32_t)off) {
+            incl.x += ox;
+            incl.y += oy;
+        }
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        uint2 run = make_uint2(0, 0);
+        for (int w = 0; w < kScanThreads / 64; w++) {
+            const uint2 t = s_wave[w];
+            s_wave[w] = run;
+            run.x += t.x;
+            run.y += t.y;
+        }
+        s_total = run;
+    }
+    __syncthreads();
+    uint2 offset = make_uint2(s_wave[tid >> 6].x + incl.x - mine.x, s_wave[tid >> 6].y + incl.y - mine.y);
+    const uint32_t all_aligned = s_total.x;
+
+    // pass 2: write the group records
+    uint32_t carry = first ? grp_data[first - 1].count[0] : 0;  // read before any write of this run's neighbours
+    __syncthreads();
+    for (uint32_t pos = first; pos < last; pos++) {
+        rt_group_data grp;
+        const uint32_t end = grp_data[pos].count[0];
+        grp.base[0] = carry;
+        carry = end;
+        const uint32_t main_count = end - grp.base[0];
+        grp.base[1] = grp_data[pos].offset[1] - main_count;
+        const uint32_t tot = main_count + grp_data[pos].count[1];
+        uint32_t tail = tot;
+        if (pos != n - 1) tail %= warp;
+        grp.count[0] = tot - tail;
+        grp.count[1] = tail;
+        grp.offset[0] = offset.x;
+        grp.offset[1] = offset.y + all_aligned;
+        offset.x += grp.count[0];
+        offset.y += grp.count[1];
+        if (!pos) {
+            glob->g.pixel_offset += glob->g.pixel_count;
+            glob->g.pixel_count = grp.count[0];
+        }
+        grp_data[pos] = grp;
+    }
+    if (tid == 0) {
+        glob->g.old_count = glob->g.ray_count;
+        glob->g.ray_count = all_aligned;
+    }
+}
+
+// set_ray_index (ray-tracer.cl:293-302)
+__global__ void k_set_ray_index(const DevGlobal *glob, const rt_group_data *grp_data, const rt_index_pair *src,
+                                rt_index_pair *dst, uint32_t count)
+{
+    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= count) return;
+    const rt_index_pair e = src[index];
+    const rt_group_data grp = grp_data[e.key & kIdMask];
+    index -= (index < glob->g.old_count ? grp.base[0] : grp.base[1]);
+    if (index < grp.count[1]) index += grp.offset[1];
+    else index += grp.offset[0] - grp.count[1];
+    dst[index] = e;
+}
+
+// Converts ray slots to the reference's RayQueue layout (ray-tracer.h:164-170) for rt_dump_state.
+__global__ void k_export_rays(const RaySlot *rays, rt_ray_queue *out, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const RaySlot &s = rays[i];
+    rt_ray_queue q;
+    q.weight[0] = s.weight.x;  q.weight[1] = s.weight.y;  q.weight[2] = s.weight.z;  q.weight[3] = s.weight.w;
+    q.pixel = s.pixel;  q.type = s.type;  q.material_id = s.material_id;  q.queue_len = s.queue_len;
+    q.start_min[0] = s.start_min.x;  q.start_min[1] = s.start_min.y;  q.start_min[2] = s.start_min.z;  q.start_min[3] = s.start_min.w;
+    q.dir_max[0] = s.dir_max.x;  q.dir_max[1] = s.dir_max.y;  q.dir_max[2] = s.dir_max.z;  q.dir_max[3] = s.dir_max.w;
+    q.norm[0] = s.norm.x;  q.norm[1] = s.norm.y;  q.norm[2] = s.norm.z;  q.norm[3] = s.norm.w;
+    q.root = rt_ray_hit{s.root.pos, s.root.group_id, {s.root.local0, s.root.local1}};
+    q.orig = rt_ray_hit{s.orig.pos, s.orig.group_id, {s.orig.local0, s.orig.local1}};
+    for (int k = 0; k < RT_MAX_QUEUE_LEN; k++)
+        q.queue[k] = rt_ray_hit{s.queue[k].pos, s.queue[k].group_id, {s.queue[k].local0, s.queue[k].local1}};
+    out[i] = q;
+}
+
+}  // namespace rtd
+
+// ---------------------------------------------------------------- launchers (used by rt_api.hip)
+
+#include "rt_launch.h"
+
+namespace rtd {
+
+static inline dim3 grid_for(uint32_t count, uint32_t block) { return dim3((count + block - 1) / block); }
+
+void launch_init_frame(const LaunchCtx &c)
+{
+    ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
+    k_init_groups<<<grid_for(c.group_count, 256), 256, 0, c.stream>>>(c.grp_data, c.group_count);
+    k_init_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
+    hipMemsetAsync(c.frame.area, 0, sizeof(float4) * size_t(c.area_size), c.stream);
+}
+
+void launch_load_rays(const LaunchCtx &c, const rt_ray *rays, uint32_t n_rays)
+{
+    ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
+    k_init_groups<<<grid_for(c.group_count, 256), 256, 0, c.stream>>>(c.grp_data, c.group_count);
+    k_load_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool, rays, n_rays);
+}
+
+void launch_process_traverse(const LaunchCtx &c)
+{
+    ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
+    k_process_aabb<<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a);
+}
+
+void launch_process_misc(const LaunchCtx &c)
+{
+    ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
+    k_process_misc<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
+}
+
+void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst)
+{
+    launch_compact_raw(c.stream, c.frame.glob, c.grp_data, sorted, dst, c.pool, c.group_count);
+}
+
+void launch_compact_raw(hipStream_t stream, DevGlobal *glob, rt_group_data *grp_data, const rt_index_pair *sorted,
+                        rt_index_pair *dst, uint32_t count, uint32_t group_count)
+{
+    k_count_groups<<<grid_for(group_count, 256), 256, 0, stream>>>(glob, grp_data, sorted);
+    k_update_groups<<<1, kScanThreads, 0, stream>>>(glob, grp_data);
+    k_set_ray_index<<<grid_for(count, 256), 256, 0, stream>>>(glob, grp_data, sorted, dst, count);
+}
+
+void launch_resolve(const LaunchCtx &c, void *out)
+{
+    k_resolve_rgba8<<<grid_for(c.area_size, 256), 256, 0, c.stream>>>(c.frame.area, static_cast<uchar4 *>(out), c.area_size);
+}
+
+void launch_export_rays(const LaunchCtx &c, rt_ray_queue *out)
+{
+    k_export_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(c.frame.rays, out, c.pool);
+}
+
+}  // namespace rtd

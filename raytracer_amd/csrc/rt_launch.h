@@ -1,0 +1,39 @@
+// rt_launch.h -- host-callable launchers of the kernels in rt_kernels.hip and rt_sort.hip.
+#pragma once
+
+#include "rt_device.h"
+
+namespace rtd {
+
+struct LaunchCtx {
+    hipStream_t stream;
+    Scene scene;
+    Frame frame;
+    rt_camera cam;
+    rt_group_data *grp_data;
+    uint32_t pool, area_size, group_count;
+};
+
+void launch_init_frame(const LaunchCtx &c);
+void launch_load_rays(const LaunchCtx &c, const rt_ray *rays_dev, uint32_t n_rays);
+void launch_process_traverse(const LaunchCtx &c);
+void launch_process_misc(const LaunchCtx &c);
+void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst);
+void launch_compact_raw(hipStream_t stream, DevGlobal *glob, rt_group_data *grp_data, const rt_index_pair *sorted,
+                        rt_index_pair *dst, uint32_t count, uint32_t group_count);
+void launch_resolve(const LaunchCtx &c, void *out_dev);
+void launch_export_rays(const LaunchCtx &c, rt_ray_queue *out_dev);
+
+// Radix sort of (key, slot) pairs, see rt_sort.hip.
+struct SortWorkspace {
+    uint32_t *counts;   // [256][tiles] per-tile digit counts, scanned in place
+    uint32_t *totals;   // [256] per-digit totals of a pass
+    rt_index_pair *tmp; // one pool-sized ping-pong buffer
+    uint32_t tiles;     // capacity in tiles of RT_SORT_TILE pairs
+};
+// Sorts the first *n_dev of `count` pairs of `in` into `out`; pairs beyond are copied through.
+void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pair *in, rt_index_pair *out,
+                 uint32_t count, const uint32_t *n_dev, uint32_t group_count);
+uint32_t sort_key_bits(uint32_t group_count);
+
+}  // namespace rtd

@@ -1,0 +1,243 @@
+// rt_sort.hip -- the ray-key sort as an LDS-staged LSD radix sort for gfx950.
+//
+// Output contract (what sort.cl:19-102 driven by main.cpp:444-463 produces): the first n pairs, read
+// tile by tile (8,192 pairs) in the thread-major order of local_count (thread t of a tile owns pairs
+// 512*i + t, sort.cl:26-27), stably sorted by the low key bits that cover group_count groups; pairs
+// [n, count) unchanged.  The reference gets there with 5-bit digits and three launches per digit, a
+// 512-wide scan per bin and a single-work-group global scan.  Here:
+//   * 8-bit digits (two passes for up to 65,536 groups instead of three or four);
+//   * per pass: tile histograms -> per-digit scan over tiles -> scatter;
+//   * the scatter stages its tile in LDS (in logical, i.e. thread-major, order on the first pass),
+//     ranks 64 keys at a time with wave ballots (match-any on the digit) against per-wave LDS
+//     counters, orders the tile in LDS and writes each digit's run to HBM contiguously.
+#include "rt_launch.h"
+
+namespace rtd {
+
+constexpr uint32_t kTile = RT_SORT_TILE;
+constexpr uint32_t kSortThreads = 512;
+constexpr uint32_t kSortWaves = kSortThreads / 64;
+constexpr uint32_t kPerThread = kTile / kSortThreads;  // 16
+constexpr uint32_t kRadixBits = 8;
+constexpr uint32_t kRadix = 1u << kRadixBits;
+
+// Key bits the reference's pass loop covers: 5 bits per pass while (group_count-1) >> 5p is non-zero,
+// at most the 24 id bits (main.cpp:444-445).
+uint32_t sort_key_bits(uint32_t group_count)
+{
+    uint32_t passes = 0;
+    for (uint32_t max = group_count - 1; max; max >>= 5) passes++;
+    const uint32_t bits = 5 * passes;
+    return bits > 24 ? 24 : bits;
+}
+
+// Exclusive prefix of v over the block (all threads must call); total = sum over the block.
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave, uint32_t &total)
+{
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= (uint32_t)off) incl += o;
+    }
+    __syncthreads();  // s_wave may still be in use by a previous call
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < THREADS / 64; k++) {
+        const uint32_t t = s_wave[k];
+        if (k < w) before += t;
+        all += t;
+    }
+    total = all;
+    return before + incl - v;
+}
+
+// Per-tile digit histogram of one pass: counts[digit * tiles + tile].
+__global__ __launch_bounds__(kSortThreads) void k_sort_count(const rt_index_pair *src, const uint32_t *n_ptr,
+                                                             uint32_t *counts, uint32_t tiles, uint32_t shift, uint32_t mask)
+{
+    __shared__ uint32_t hist[kRadix];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, base = tile * kTile, n = *n_ptr;
+    if (base >= n) return;
+    if (tid < kRadix) hist[tid] = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t i = 0; i < kPerThread; i++) {
+        const uint32_t p = base + i * kSortThreads + tid;
+        if (p < n) atomicAdd(&hist[(src[p].key >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    if (tid < kRadix) counts[tid * tiles + tile] = hist[tid];
+}
+
+// One block per digit: exclusive scan of that digit's counts over the active tiles, and its total.
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t *counts, uint32_t *totals, const uint32_t *n_ptr, uint32_t tiles)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x, n = *n_ptr;
+    const uint32_t active = (n + kTile - 1) / kTile;
+    uint32_t *row = counts + blockIdx.x * tiles;
+    const uint32_t per = (active + 255) / 256;
+    const uint32_t first = tid * per < active ? tid * per : active;
+    const uint32_t last = first + per < active ? first + per : active;
+    uint32_t sum = 0;
+    for (uint32_t i = first; i < last; i++) sum += row[i];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<256>(sum, s_wave, total);
+    for (uint32_t i = first; i < last; i++) {
+        const uint32_t t = row[i];
+        row[i] = run;
+        run += t;
+    }
+    if (tid == 0) totals[blockIdx.x] = total;
+}
+
+// Scatter of one pass.  first_pass: read the tile in the reference's thread-major order.
+// tail_src (final pass only): where pairs at or beyond n are copied from.
+__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const rt_index_pair *src, rt_index_pair *dst,
+                                                               const rt_index_pair *tail_src, const uint32_t *n_ptr,
+                                                               const uint32_t *counts, const uint32_t *totals,
+                                                               uint32_t tiles, uint32_t shift, uint32_t mask,
+                                                               uint32_t first_pass)
+{
+    // The tile, one padding slot after every 16 pairs: the transposing store (stride 16 pairs per
+    // thread) and the linear 8-byte reads are then both free of bank conflicts.
+    __shared__ uint2 s_tile[kTile + kTile / 16];
+    __shared__ uint32_t s_cnt[kSortWaves * kRadix];  // per wave and digit: running count, later the wave's base
+    __shared__ uint32_t s_start[kRadix];             // first position of the digit inside the ordered tile
+    __shared__ uint32_t s_gbase[kRadix];             // destination of the digit's run minus s_start
+    __shared__ uint32_t s_wave[kSortWaves];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t tile = blockIdx.x, base = tile * kTile, n = *n_ptr;
+    const uint32_t m = base >= n ? 0 : (n - base < kTile ? n - base : kTile);
+
+    if (tail_src) {
+#pragma unroll 4
+        for (uint32_t i = 0; i < kPerThread; i++) {
+            const uint32_t p = i * kSortThreads + tid;
+            if (p >= m) dst[base + p] = tail_src[base + p];
+        }
+    }
+    if (m == 0) return;
+
+    for (uint32_t i = tid; i < kSortWaves * kRadix; i += kSortThreads) s_cnt[i] = 0;
+
+    // Stage the tile.  Thread t of a (possibly ragged) tile owns `mine` pairs 512*i + t; in logical
+    // order they are consecutive, after the pairs of lower threads (inverse of sort.cl:72-82).
+    {
+        const uint32_t each = m / kSortThreads, extra = m % kSortThreads;
+        const uint32_t mine = each + (tid < extra ? 1 : 0);
+        const uint32_t q0 = tid < extra ? tid * (each + 1) : extra * (each + 1) + (tid - extra) * each;
+#pragma unroll 4
+        for (uint32_t i = 0; i < kPerThread; i++) {
+            if (i >= mine) break;
+            const uint32_t p = i * kSortThreads + tid;
+            const uint32_t q = first_pass ? q0 + i : p;
+            const rt_index_pair e = src[base + p];
+            s_tile[q + (q >> 4)] = make_uint2(e.key, e.slot);
+        }
+    }
+    __syncthreads();
+
+    // Rank: wave w owns logical positions [1024 w, 1024 w + 1024), 64 at a time.
+    uint32_t keys[kPerThread], vals[kPerThread], ranks[kPerThread];
+    const unsigned long long lanes_below = (1ull << lane) - 1;
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; r++) {
+        const uint32_t q = w * (kTile / kSortWaves) + r * 64 + lane;
+        const bool valid = q < m;
+        uint2 e = make_uint2(0, 0);
+        if (valid) e = s_tile[q + (q >> 4)];
+        const uint32_t d = (e.x >> shift) & mask;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (uint32_t b = 0; b < kRadixBits; b++) {
+            const bool bit = (d >> b) & 1;
+            const unsigned long long vote = __ballot(bit);
+            peers &= bit ? vote : ~vote;
+        }
+        const uint32_t before = s_cnt[w * kRadix + d];
+        const uint32_t below = __popcll(peers & lanes_below);
+        if (valid && below == 0) s_cnt[w * kRadix + d] = before + __popcll(peers);
+        keys[r] = e.x;
+        vals[r] = e.y;
+        ranks[r] = before + below;
+    }
+    __syncthreads();
+
+    // Per digit: turn the waves' counts into bases, get the tile's count.
+    uint32_t digit_count = 0;
+    if (tid < kRadix) {
+#pragma unroll
+        for (uint32_t k = 0; k < kSortWaves; k++) {
+            const uint32_t t = s_cnt[k * kRadix + tid];
+            s_cnt[k * kRadix + tid] = digit_count;
+            digit_count += t;
+        }
+    }
+    uint32_t unused;
+    const uint32_t start = block_exclusive_scan<kSortThreads>(digit_count, s_wave, unused);
+    const uint32_t digit_base = block_exclusive_scan<kSortThreads>(tid < kRadix ? totals[tid] : 0u, s_wave, unused);
+    if (tid < kRadix) {
+        s_start[tid] = start;
+        s_gbase[tid] = digit_base + counts[tid * tiles + tile] - start;
+    }
+    __syncthreads();
+
+    // Order the tile in LDS, then write each digit's run contiguously.
+#pragma unroll
+    for (uint32_t r = 0; r < kPerThread; r++) {
+        const uint32_t q = w * (kTile / kSortWaves) + r * 64 + lane;
+        if (q < m) {
+            const uint32_t d = (keys[r] >> shift) & mask;
+            s_tile[s_start[d] + s_cnt[w * kRadix + d] + ranks[r]] = make_uint2(keys[r], vals[r]);
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (uint32_t i = 0; i < kPerThread; i++) {
+        const uint32_t j = i * kSortThreads + tid;
+        if (j < m) {
+            const uint2 e = s_tile[j];
+            dst[s_gbase[(e.x >> shift) & mask] + j] = rt_index_pair{e.x, e.y};
+        }
+    }
+}
+
+__global__ void k_copy_pairs(const rt_index_pair *src, rt_index_pair *dst, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[i];
+}
+
+void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pair *in, rt_index_pair *out, uint32_t count,
+                 const uint32_t *n_dev, uint32_t group_count)
+{
+    const uint32_t bits = sort_key_bits(group_count);
+    const uint32_t passes = (bits + kRadixBits - 1) / kRadixBits;
+    if (passes == 0) {
+        k_copy_pairs<<<(count + 255) / 256, 256, 0, stream>>>(in, out, count);
+        return;
+    }
+    const uint32_t tiles = count / kTile;
+    const rt_index_pair *src = in;
+    for (uint32_t k = 0; k < passes; k++) {
+        const uint32_t shift = k * kRadixBits;
+        const uint32_t width = bits - shift < kRadixBits ? bits - shift : kRadixBits;
+        const uint32_t mask = (1u << width) - 1;
+        const bool final_pass = k + 1 == passes;
+        rt_index_pair *dst = ((passes - 1 - k) % 2 == 0) ? out : ws.tmp;
+        k_sort_count<<<tiles, kSortThreads, 0, stream>>>(src, n_dev, ws.counts, ws.tiles, shift, mask);
+        k_sort_scan<<<kRadix, 256, 0, stream>>>(ws.counts, ws.totals, n_dev, ws.tiles);
+        k_sort_scatter<<<tiles, kSortThreads, 0, stream>>>(src, dst, final_pass ? in : nullptr, n_dev, ws.counts, ws.totals,
+                                                           ws.tiles, shift, mask, k == 0 ? 1u : 0u);
+        src = dst;
+    }
+}
+
+}  // namespace rtd
