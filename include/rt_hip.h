@@ -102,6 +102,8 @@ typedef struct {
     uint64_t primary_spawned; /* samples started: sum of pixel_count, cf. main.cpp:538-540 */
     uint64_t shadow_spawned;  /* mat_shader invocations (shader.cl:20-35) */
     uint64_t steps;           /* make_step calls so far */
+    uint64_t box_tests;       /* boxes scanned by aabb_shader, summed over rays (shader.cl:84-99) */
+    uint64_t tri_tests;       /* triangles scanned by mesh_shader, summed over rays (shader.cl:123-133) */
 } rt_counters;
 
 /* -------------------------------------------------------------- lifecycle */

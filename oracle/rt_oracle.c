@@ -459,6 +459,8 @@ static void k_process(orc_ctx *c, rt_index_pair *ray_index)
     c->work.shadows += total.shadows;
     c->counters.primary_spawned += total.spawned;
     c->counters.shadow_spawned += total.shadows;
+    c->counters.box_tests += total.box_tests;
+    c->counters.tri_tests += total.tri_tests;
 }
 
 /* ------------------------------------------------------------------ sort (sort.cl) */

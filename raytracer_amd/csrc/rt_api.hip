@@ -388,7 +388,7 @@ int rt_init_frame(rt_ctx *c)
     if (!c->scene_ready) return fail(c, RT_ERR_NOT_READY, "rt_init_frame before rt_upload_scene");
     RT_HIP(c, hipSetDevice(c->cfg.device));
     RT_HIP(c, hipMemsetAsync(reinterpret_cast<char *>(c->glob) + offsetof(DevGlobal, primary_spawned), 0,
-                             2 * sizeof(unsigned long long), c->stream));
+                             4 * sizeof(unsigned long long), c->stream));
     launch_init_frame(launch_ctx(c));
     c->steps = 0;
     c->frame_ready = true;
@@ -472,6 +472,8 @@ int rt_get_counters(rt_ctx *c, rt_counters *dst)
     dst->primary_spawned = g.primary_spawned;
     dst->shadow_spawned = g.shadow_spawned;
     dst->steps = c->steps;
+    dst->box_tests = g.box_tests;
+    dst->tri_tests = g.tri_tests;
     return RT_OK;
 }
 

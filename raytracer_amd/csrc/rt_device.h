@@ -54,6 +54,7 @@ struct alignas(16) DevGlobal {
     uint32_t warp_width, sample_limit, hit_capacity, row_offset;
     uint32_t mode, sort_count, pad0, pad1;  // sort_count: element count for stand-alone sort calls
     unsigned long long primary_spawned, shadow_spawned;
+    unsigned long long box_tests, tri_tests;  // boxes / triangles scanned, summed over rays (work counters)
 };
 
 struct Scene {

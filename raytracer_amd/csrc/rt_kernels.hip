@@ -94,11 +94,12 @@ __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlob
     return reset_ray(ray, cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
 }
 
-// One atomic per wave for a per-lane event count.
-__device__ __forceinline__ void count_lanes(unsigned long long *counter, bool flag)
+// One atomic per wave for a per-lane event count (each counted lane adds `weight`, wave-uniform).
+__device__ __forceinline__ void count_lanes(unsigned long long *counter, bool flag, uint32_t weight = 1)
 {
     const unsigned long long mask = __ballot(flag);
-    if (flag && lane_id() == (uint32_t)(__ffsll((long long)mask) - 1)) atomicAdd(counter, (unsigned long long)__popcll(mask));
+    if (flag && lane_id() == (uint32_t)(__ffsll((long long)mask) - 1))
+        atomicAdd(counter, (unsigned long long)__popcll(mask) * weight);
 }
 
 // ---------------------------------------------------------------- frame kernels
@@ -300,6 +301,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     const RayHit head = ray->queue[0];
     const LocalRay lr = make_local(g, ray, head.local0, a.scene.mat);
 
+    count_lanes(&a.frame.glob->tri_tests, true, grp.z);
     ConstPtr<f32x4> rec = const_ptr<f32x4>(a.scene.tri_rec + grp.y);  // three 16-byte words per triangle
     float best = lr.tmax, hit_u = 0, hit_v = 0;
     uint32_t hit_index = 0xFFFFFFFFu;
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a)
         const LocalRay lr = make_local(g, ray, head.local0, a.scene.mat);
         const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
 
+        count_lanes(&a.frame.glob->box_tests, true, grp.y);
         ConstPtr<f32x8> box = const_ptr<f32x8>(a.scene.aabb + grp.x);  // min.xyz, group id, max.xyz, local id
         uint32_t n = 0;
         bool too_many = false;
@@ -706,7 +709,7 @@ void launch_init_frame(const LaunchCtx &c)
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
     k_init_groups<<<grid_for(c.group_count, 256), 256, 0, c.stream>>>(c.grp_data, c.group_count);
     k_init_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
-    hipMemsetAsync(c.frame.area, 0, sizeof(float4) * size_t(c.area_size), c.stream);
+    (void)hipMemsetAsync(c.frame.area, 0, sizeof(float4) * size_t(c.area_size), c.stream);
 }
 
 void launch_load_rays(const LaunchCtx &c, const rt_ray *rays, uint32_t n_rays)

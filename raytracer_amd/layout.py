@@ -33,7 +33,8 @@ ray_queue_dtype = np.dtype([("weight", f32, 4), ("pixel", u32), ("type", u32), (
 index_pair_dtype = np.dtype([("key", u32), ("slot", u32)])
 hit_record_dtype = np.dtype([("t", f32), ("leaf_group", u32), ("instance", u32), ("tri", u32)])
 ray_dtype = np.dtype([("start_min", f32, 4), ("dir_max", f32, 4)])
-counters_dtype = np.dtype([("primary_spawned", np.uint64), ("shadow_spawned", np.uint64), ("steps", np.uint64)])
+counters_dtype = np.dtype([("primary_spawned", np.uint64), ("shadow_spawned", np.uint64), ("steps", np.uint64),
+                           ("box_tests", np.uint64), ("tri_tests", np.uint64)])
 
 assert group_dtype.itemsize == 16 and aabb_dtype.itemsize == 32 and vertex_dtype.itemsize == 32
 assert matrix_dtype.itemsize == 48 and camera_dtype.itemsize == 80 and global_dtype.itemsize == 112
