@@ -249,6 +249,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
     RT_HIP(c, dev_alloc(c->ws.counts, size_t(256) * c->ws.tiles));
     RT_HIP(c, dev_alloc(c->ws.totals, 256));
     RT_HIP(c, hipMemsetAsync(c->glob, 0, sizeof(DevGlobal), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->hits, 0, sizeof(rt_hit_record) * size_t(cfg->hit_capacity ? cfg->hit_capacity : 1), c->stream));
     RT_HIP(c, hipMemsetAsync(c->rays, 0, sizeof(RaySlot) * size_t(c->pool), c->stream));
     RT_HIP(c, hipMemsetAsync(c->area, 0, sizeof(float4) * size_t(c->area_size), c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));

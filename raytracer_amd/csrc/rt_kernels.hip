@@ -631,7 +631,8 @@ __global__ __launch_bounds__(kScanThreads) void k_update_groups(DevGlobal *glob,
     const uint32_t all_aligned = s_total.x;
 
     // pass 2: write the group records
-    uint32_t carry = first ? grp_data[first - 1].count[0] : 0;  // read before any write of this run's neighbours
+    // end of the previous run, read before any thread writes (threads past the last group own nothing)
+    uint32_t carry = (first && first < n) ? grp_data[first - 1].count[0] : 0;
     __syncthreads();
     for (uint32_t pos = first; pos < last; pos++) {
         rt_group_data grp;
@@ -672,7 +673,7 @@ __global__ void k_set_ray_index(const DevGlobal *glob, const rt_group_data *grp_
     index -= (index < glob->g.old_count ? grp.base[0] : grp.base[1]);
     if (index < grp.count[1]) index += grp.offset[1];
     else index += grp.offset[0] - grp.count[1];
-    dst[index] = e;
+    if (index < count) dst[index] = e;  // always true for consistent group data; keeps bad caller data from faulting
 }
 
 // Converts ray slots to the reference's RayQueue layout (ray-tracer.h:164-170) for rt_dump_state.

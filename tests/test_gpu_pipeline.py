@@ -1,0 +1,219 @@
+"""The whole hot path on the GPU through the C ABI against the oracle: state after every step,
+finished frames, per-sample hit records, closest-hit queries, and properties at the headline size."""
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import api, layout as L, scene as S
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def assert_same_state(rt, o, step):
+    """Integer state bit-exact; float state bit-exact too (same operations in the same order) except
+    the accumulator, whose atomic adds may arrive in a different order within a step."""
+    rays, index, groups = rt.dump_state()
+    assert H.same_bytes(rt.global_data(), o.global_data), step
+    assert H.same_bytes(index, o.ray_index), step
+    assert H.same_bytes(groups, o.grp_data), step
+    assert H.ray_fields_equal(rays, o.ray_list) == [], step
+
+
+def test_state_matches_oracle_step_by_step(bunny_scene_128):
+    from oracle import pyoracle as O
+    cap = 16384 * 4
+    rt = api.RayTracer(bunny_scene_128, warp_width=32, hit_capacity=cap)
+    o = O.Oracle(bunny_scene_128, warp_width=32, hit_capacity=cap)
+    rt.init_frame(); o.init_frame()
+    assert_same_state(rt, o, -1)
+    for step in range(48):
+        rt.make_step(1); o.step(1)
+        assert_same_state(rt, o, step)
+    assert np.allclose(rt.area(), o.area, rtol=1e-5, atol=1e-6)
+    assert H.same_bytes(rt.hits(), o.hits)
+    c, oc = rt.counters(), o.counters()
+    for k in ("primary_spawned", "shadow_spawned", "steps", "box_tests", "tri_tests"):
+        assert int(c[k]) == int(oc[k]), k
+    assert rt.current_ray() == int(o.global_data["pixel_offset"][0])
+    assert np.abs(rt.draw_frame().astype(int) - o.resolve_rgba8().astype(int)).max() <= 1
+    rt.close(); o.close()
+
+
+def test_state_matches_oracle_with_second_model(standin_ply):
+    from oracle import pyoracle as O
+    sc = S.build_scene([S.BUNNY, standin_ply], 128, 128, 16384)
+    rt = api.RayTracer(sc, warp_width=32)
+    o = O.Oracle(sc, warp_width=32)
+    rt.init_frame(); o.init_frame()
+    for chunk in range(6):
+        rt.make_step(8); o.step(8)
+        assert_same_state(rt, o, chunk)
+    rt.close(); o.close()
+
+
+def test_pipeline_golden_state(bunny_scene_128):
+    g = np.load(os.path.join(GOLDEN, "pipeline_bunny128.npz"))
+    rt = api.RayTracer(bunny_scene_128, warp_width=int(g["warp_width"]), hit_capacity=len(g["hits"]))
+    rt.init_frame()
+    rt.make_step(int(g["steps"]))
+    rays, index, groups = rt.dump_state()
+    assert H.same_bytes(rt.global_data(), g["global_data"])
+    assert H.same_bytes(index, g["ray_index"]) and H.same_bytes(groups, g["grp_data"])
+    assert H.same_bytes(rt.hits(), g["hits"])
+    assert np.allclose(rt.area(), g["area"], rtol=1e-5, atol=1e-6)
+    import hashlib
+    for name, digest in g["ray_field_sha"]:
+        assert hashlib.sha256(np.ascontiguousarray(rays[str(name)]).tobytes()).hexdigest() == str(digest), name
+    rt.close()
+
+
+def run_to_completion(r, steps_parked=24, max_steps=400):
+    r.init_frame()
+    r.make_step(steps_parked)
+    r.set_warp_width(1)
+    r.make_step(1)
+    steps = steps_parked + 1
+    while int(r.global_data()["ray_count"][0]):
+        r.make_step(1)
+        steps += 1
+        assert steps < max_steps
+    return steps
+
+
+def test_finished_frame_golden(bunny_scene_64):
+    g = np.load(os.path.join(GOLDEN, "drain_bunny64.npz"))
+    limit = int(g["sample_limit"])
+    rt = api.RayTracer(bunny_scene_64, warp_width=32, sample_limit=limit, hit_capacity=limit)
+    assert run_to_completion(rt) == int(g["steps"])
+    assert H.same_bytes(rt.hits(), g["hits"])                                    # ids exact, t exact
+    assert np.allclose(rt.area(), g["area"], rtol=1e-5, atol=1e-6)              # colour sums
+    assert np.abs(rt.draw_frame().astype(int) - g["image"].astype(int)).max() <= 1  # 1 LSB at 8 bit
+    c = rt.counters()
+    gc = g["counters"][0]
+    assert int(c["primary_spawned"]) == limit == int(gc["primary_spawned"])
+    assert int(c["shadow_spawned"]) == int(gc["shadow_spawned"])
+    rt.close()
+
+
+def test_wave64_schedule_gives_the_same_samples(bunny_scene_64):
+    """Production granularity (64) and odd granularities change the schedule, never a sample's hit."""
+    g = np.load(os.path.join(GOLDEN, "drain_bunny64.npz"))
+    limit = int(g["sample_limit"])
+    for warp, parked in ((64, 12), (1, 2), (48, 9)):
+        rt = api.RayTracer(bunny_scene_64, warp_width=warp, sample_limit=limit, hit_capacity=limit)
+        run_to_completion(rt, steps_parked=parked)
+        assert H.same_bytes(rt.hits(), g["hits"]), warp
+        assert np.allclose(rt.area(), g["area"], rtol=1e-5, atol=1e-6), warp
+        assert np.abs(rt.draw_frame().astype(int) - g["image"].astype(int)).max() <= 1, warp
+        rt.close()
+
+
+def test_trace_closest_matches_oracle_and_brute_force(bunny_scene_64):
+    from oracle import pyoracle as O
+    from test_oracle_pipeline import camera_rays
+    sc = bunny_scene_64
+    rng = np.random.default_rng(21)
+    rays = camera_rays(sc, 3000, rng)
+    # add incoherent rays: random origins inside the field, random directions
+    extra = np.zeros(2000, L.ray_dtype)
+    extra["start_min"][:, 0] = rng.uniform(-2, 2, 2000)
+    extra["start_min"][:, 1] = rng.uniform(0, 4, 2000)
+    extra["start_min"][:, 2] = rng.uniform(-1, 1, 2000)
+    extra["start_min"][:, 3] = 0.001
+    d = rng.normal(size=(2000, 3))
+    extra["dir_max"][:, :3] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    extra["dir_max"][:, 3] = np.inf
+    rays = np.concatenate([rays, extra])
+    rt = api.RayTracer(sc, warp_width=64)
+    got = rt.trace_closest(rays)
+    o = O.Oracle(sc, warp_width=32)
+    want = o.trace_closest(rays)
+    assert H.same_bytes(got, want)            # t, leaf, instance, triangle: all bit-exact
+    sub = np.arange(0, len(rays), 25)
+    brute = H.brute_force_closest(sc, rays[sub])
+    hit = np.isfinite(brute)
+    assert np.array_equal(np.isfinite(got["t"][sub]), hit)
+    assert np.allclose(got["t"][sub][hit], brute[hit], rtol=1e-4)
+    # the context is reusable for a frame afterwards
+    rt.init_frame(); rt.make_step(4)
+    assert int(rt.global_data()["ray_count"][0]) > 0
+    assert len(rt.trace_closest(np.zeros(0, L.ray_dtype))) == 0
+    rt.close(); o.close()
+
+
+def test_api_errors(bunny_scene_64):
+    rt = api.RayTracer(bunny_scene_64)
+    with pytest.raises(api.RtError, match="RT_ERR_NOT_READY"):
+        rt.make_step(1)                       # before init_frame
+    with pytest.raises(api.RtError, match="RT_ERR_INVALID_VALUE"):
+        rt.trace_closest(np.zeros(rt.pool + 1, L.ray_dtype))
+    bad = S.build_scene([S.BUNNY], 64, 64, 8192, n_obj=4)
+    bad.aabbs["group_id"][0] = 0x40FFFFF0     # box pointing outside the group table
+    with pytest.raises(api.RtError, match="RT_ERR_INVALID_VALUE"):
+        rt.upload(bad)
+    other = S.build_scene([S.BUNNY], 32, 32, 8192, n_obj=4)
+    with pytest.raises(api.RtError, match="does not match"):
+        rt.upload(other)                      # camera size differs from the context
+    rt.close()
+
+
+def test_band_contexts_reproduce_the_full_frame():
+    """Two row bands (as two GPUs would render them) give the full frame's samples: same hit records
+    per pixel sample, same image."""
+    W, Hh = 64, 64
+    limit = W * Hh
+    full_sc = S.build_scene([S.BUNNY, S.BUNNY], W, Hh, 8192)
+    full = api.RayTracer(full_sc, warp_width=64, sample_limit=limit, hit_capacity=limit)
+    run_to_completion(full, steps_parked=8)
+    image = full.draw_frame()
+    area = full.area()
+    hits = full.hits()
+    full.close()
+    parts, part_hits = [], []
+    for first in (0, 40):
+        rows = 40 if first == 0 else 24
+        sc = S.build_scene([S.BUNNY, S.BUNNY], W, Hh, 8192, band_first=first, band_rows=rows)
+        rt = api.RayTracer(sc, warp_width=64, sample_limit=W * rows, hit_capacity=W * rows)
+        run_to_completion(rt, steps_parked=8)
+        parts.append(rt.area())
+        part_hits.append(rt.hits())
+        assert np.abs(rt.draw_frame().astype(int) - image[first:first + rows].astype(int)).max() <= 1
+        rt.close()
+    assert np.allclose(np.concatenate(parts), area, rtol=1e-5, atol=1e-6)
+    assert H.same_bytes(np.concatenate(part_hits), hits)
+
+
+def test_headline_size_properties(standin_ply):
+    """1920x1080, 2,080,768 slots, bunny + (reduced) second model: invariants that do not need the oracle."""
+    sc = S.build_scene([S.BUNNY, standin_ply], 1920, 1080, 1920 * 1080)
+    rt = api.RayTracer(sc, warp_width=64)
+    rt.init_frame()
+    pool = rt.pool
+    assert pool == 2080768
+    prev = pool
+    for chunk in range(4):
+        rt.make_step(16)
+        g = rt.global_data()[0]
+        n = int(g["ray_count"])
+        assert n <= pool and n % 64 == 0
+        rays, index, groups = rt.dump_state(rays=(chunk == 3))
+        ids = index["key"][:n] & L.GROUP_ID_MASK
+        assert np.all(np.diff(ids.astype(np.int64)) >= 0)
+        assert np.all(ids.reshape(-1, 64).min(axis=1) == ids.reshape(-1, 64).max(axis=1))
+        assert np.array_equal(np.sort(index["slot"]), np.arange(pool, dtype=np.uint32))
+        assert int(groups["count"][:, 0].sum()) == n and n + int(groups["count"][:, 1].sum()) == pool
+        assert int(g["pixel_offset"]) >= prev
+        prev = int(g["pixel_offset"])
+    assert np.array_equal(rays["queue"]["group_id"][index["slot"], 0], index["key"])
+    assert np.all((rays["queue_len"] >= 1) & (rays["queue_len"] <= 8))
+    c = rt.counters()
+    assert int(c["primary_spawned"]) == prev + int(rt.global_data()["pixel_count"][0]) - 0 or int(c["primary_spawned"]) == prev
+    area = rt.area()
+    assert np.isfinite(area).all() and area[:, 3].max() > 0
+    img = rt.draw_frame()
+    assert img.shape == (1080, 1920, 4) and img[..., :3].max() > 100
+    rt.close()

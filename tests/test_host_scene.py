@@ -1,0 +1,110 @@
+"""Host-side scene build (raytracer_amd/host): pinned byte for byte against a real build of the
+reference's model.cpp (oracle/_ref/libref_model.so) and against digests of that build committed
+under tests/golden/."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from raytracer_amd import layout as L, scene as S
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def scene_digests(sc):
+    kinds = {}
+    for gid in list(sc.aabbs["group_id"]) + [int(sc.data["cam"]["root_group"][0])]:
+        kinds[int(gid) & L.GROUP_ID_MASK] = (int(gid) >> L.GROUP_SH_SHIFT) & 0xF
+    w = sc.groups["w"].copy()
+    defined = np.zeros_like(w, dtype=bool)
+    for idx, kind in kinds.items():
+        defined[idx, :3 if kind == L.SH_AABB else 4] = True
+    w[~defined] = 0
+    return {"groups": digest(w), "aabbs": digest(sc.aabbs), "vertex_pos": digest(sc.vertices["pos"][:, :3]),
+            "vertex_norm": digest(sc.vertices["norm"][:, :3]), "triangles": digest(sc.triangles),
+            "matrices": digest(sc.matrices), "counts": [len(sc.groups), len(sc.aabbs), len(sc.vertices), len(sc.triangles)],
+            "group_count": sc.group_count}
+
+
+def test_bunny_scene_shape(bunny_scene_128):
+    sc = bunny_scene_128
+    # two Model objects of the bunny: 6 + 2 * 1033 groups; one model = root of 8 boxes + 8 x 128 + 1024 leaves
+    assert len(sc.groups) == 6 + 2 * 1033
+    assert len(sc.aabbs) == 256 + 2 * 1032
+    assert len(sc.triangles) == 2 * 69451
+    assert sc.group_count == 2560 and sc.group_count % 512 == 0
+    assert int(sc.data["cam"]["root_group"][0]) == (5 | L.TR_IDENTITY << 24 | L.SH_AABB << 28)
+    root = sc.groups["w"][5]
+    assert tuple(root[:3]) == (0, 256, 1)
+    leaves = (sc.aabbs["group_id"] >> 28) == L.SH_MESH
+    tri_counts = sc.groups["w"][sc.aabbs["group_id"][leaves] & L.GROUP_ID_MASK][:, 2]
+    assert tri_counts.min() >= 64 and tri_counts.max() < 128
+
+
+def test_first_matrices_follow_glibc_random():
+    sc = S.build_scene([S.BUNNY], 64, 64, 8192, n_obj=2)
+    # first four values of glibc random() with its default seed
+    r = [1804289383, 846930886, 1681692777, 1714636915]
+    alpha = 2 * 3.14159265359 * r[0] / 2147483647
+    m = sc.matrices[0]
+    assert m["x"][0] == np.float32(np.cos(alpha)) and m["y"][0] == np.float32(np.sin(alpha))
+    assert m["x"][3] == np.float32(4.0 * r[1] / 2147483647 - 2)
+    assert m["y"][3] == np.float32(4.0 * r[2] / 2147483647)
+    assert m["z"][3] == np.float32(2.0 * r[3] / 2147483647 - 1)
+
+
+@pytest.mark.skipif(O.ref_model_lib() is None, reason="oracle/_ref/libref_model.so not built (needs /root/reference)")
+def test_builder_matches_reference_model_cpp(bunny_scene_128, standin_ply):
+    for files in ([S.BUNNY, S.BUNNY], [S.BUNNY, standin_ply]):
+        sc = bunny_scene_128 if files[1] == S.BUNNY else S.build_scene(files, 128, 128, 16384)
+        groups, aabbs, vertices, triangles = O.ref_model_build(files, sc.matrices)
+        assert np.array_equal(triangles, sc.triangles)
+        assert aabbs.tobytes() == sc.aabbs.tobytes()
+        assert np.array_equal(vertices["pos"][:, :3].view(np.uint32), sc.vertices["pos"][:, :3].view(np.uint32))
+        assert np.array_equal(vertices["norm"][:, :3].view(np.uint32), sc.vertices["norm"][:, :3].view(np.uint32))
+        # group table: the reference leaves unused words uninitialised, compare the defined ones
+        for gid in list(aabbs["group_id"]) + [int(sc.data["cam"]["root_group"][0])]:
+            idx, kind = int(gid) & L.GROUP_ID_MASK, (int(gid) >> 28) & 0xF
+            words = 3 if kind == L.SH_AABB else 4
+            assert np.array_equal(groups["w"][idx][:words], sc.groups["w"][idx][:words]), idx
+
+
+@pytest.mark.skipif(O.ref_model_lib() is None, reason="oracle/_ref/libref_model.so not built")
+def test_set_camera_matches_reference():
+    a = S.set_camera(640, 480, 0.7, (0.1, -2.0, 0.3), (0.2, 1.0, -0.1))
+    b = O.ref_set_camera(640, 480, 0.7, (0.1, -2.0, 0.3), (0.2, 1.0, -0.1))
+    for f in ("eye", "top_left", "dx", "dy"):
+        assert np.array_equal(a[f][0][:3].view(np.uint32), b[f][0][:3].view(np.uint32)), f
+    assert a["width"][0] == 640 and a["height"][0] == 480
+
+
+def test_scene_matches_golden_digests_of_the_reference_build(bunny_scene_128):
+    """Golden digests were produced from the arrays the reference's model.cpp emitted (make_golden.py)."""
+    golden = json.load(open(os.path.join(GOLDEN, "scene_bunny_digests.json")))
+    assert scene_digests(bunny_scene_128) == golden["bunny_x2"]
+
+
+def test_standin_ply_roundtrip(standin_ply):
+    sc = S.build_scene([standin_ply], 64, 64, 8192, n_obj=4)
+    assert len(sc.triangles) == 2 * 264 * 132
+    assert sc.resident_triangles == 4 * 2 * 264 * 132
+
+
+def test_band_scene_keeps_full_camera():
+    full = S.build_scene([S.BUNNY], 64, 64, 8192, n_obj=4)
+    band = S.build_scene([S.BUNNY], 64, 64, 8192, n_obj=4, band_first=16, band_rows=8)
+    assert band.row_offset == 16 and band.height == 8 and band.width == 64
+    for f in ("eye", "top_left", "dx", "dy"):
+        assert np.array_equal(full.data["cam"][f], band.data["cam"][f])
+
+
+def test_bad_model_path_is_reported():
+    with pytest.raises(RuntimeError, match="cannot load model"):
+        S.build_scene(["/nonexistent.ply"], 64, 64, 8192)
