@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from raytracer_amd import api, scene as S  # noqa: E402
+from raytracer_amd import api, scene as S, tiling  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, spec
 VALU_PEAK_TFLOPS = 157.3   # MI355X FP32 vector, spec
@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--warp-width", type=int, default=64)
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 disables it)")
     p.add_argument("--dragon", default=os.environ.get("RT_DRAGON_PLY", ""), help="path to dragon_vrip.ply if available")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo gathers through host memory: a rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     return p.parse_args()
 
 
@@ -66,12 +68,6 @@ def model_files(args, rank):
     if args.scene == "dragon":
         return [dragon, dragon], label + " x2"
     return [S.BUNNY, dragon], "bun_zipper + " + label
-
-
-def band_of(rank, world, height):
-    base, extra = divmod(height, world)
-    first = rank * base + min(rank, extra)
-    return first, base + (1 if rank < extra else 0)
 
 
 def cpu_baseline(args, files, seconds):
@@ -116,53 +112,64 @@ def main():
         args.gpus = world
 
     dist = torch = None
+    device = int(os.environ.get("RT_BENCH_DEVICE", local_rank))
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
+    tensor_device = "cuda" if args.backend == "nccl" else "cpu"
 
     files, label = model_files(args, rank)
-    first, rows = band_of(rank, world, args.height)
+    first, rows = tiling.band_of(rank, world, args.height)
     pool = S.L.align_up(args.width * args.height, S.L.SORT_TILE)
     sc = S.build_scene(files, args.width, args.height, pool, band_first=first, band_rows=rows)
-    rt = api.RayTracer(sc, device=local_rank, warp_width=args.warp_width)
+    rt = api.RayTracer(sc, device=device, warp_width=args.warp_width)
     rt.init_frame()
 
     band = frame = None
-    max_rows = -(-args.height // world)
+    max_rows = tiling.max_band_rows(world, args.height)
     if world > 1:
-        band = torch.zeros((max_rows, args.width, 4), dtype=torch.uint8, device="cuda")
-        frame = torch.zeros((world, max_rows, args.width, 4), dtype=torch.uint8, device="cuda")
+        band = torch.zeros((max_rows, args.width, 4), dtype=torch.uint8, device=tensor_device)
+        frame = torch.zeros((world, max_rows, args.width, 4), dtype=torch.uint8, device=tensor_device)
     host_band = np.zeros((rows, args.width, 4), np.uint8)
 
     def resolve_and_gather():
         if world > 1:
-            rt.draw_frame_device(band.data_ptr())
-            dist.all_gather_into_tensor(frame, band)
+            if tensor_device == "cuda":
+                rt.draw_frame_device(band.data_ptr())
+            else:
+                rt.draw_frame(host_band)
+                band[:rows] = torch.from_numpy(host_band)
+            dist.all_gather(list(frame.unbind(0)), band)
         else:
             rt.draw_frame(host_band)
 
     def barrier():
         rt.sync()
         if world > 1:
-            torch.cuda.synchronize()
+            if tensor_device == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if tensor_device == "cuda":
+                torch.cuda.synchronize()
 
     rt.make_step(args.warmup)
+    barrier()
+    t_g = time.perf_counter()
     resolve_and_gather()
     barrier()
+    gather_ms = (time.perf_counter() - t_g) * 1e3  # one resolve + gather, measured outside the timed region too
     c0 = rt.counters()
     rt.set_profiling(True)
     t0 = time.perf_counter()
     rt.make_step(args.steps)
-    t_steps = time.perf_counter()
     resolve_and_gather()
     barrier()
     dt = time.perf_counter() - t0
-    rt.sync()
-    gather_ms = (time.perf_counter() - t_steps) * 1e3
     stage_ms, timed = rt.stage_times()
     rt.set_profiling(False)
     c1 = rt.counters()
@@ -170,7 +177,7 @@ def main():
     d = {k: int(c1[k]) - int(c0[k]) for k in ("primary_spawned", "shadow_spawned", "box_tests", "tri_tests")}
     local = np.array([dt, d["primary_spawned"], d["shadow_spawned"], d["box_tests"], d["tri_tests"]], np.float64)
     if world > 1:
-        t = torch.tensor(local, dtype=torch.float64, device="cuda")
+        t = torch.tensor(local, dtype=torch.float64, device=tensor_device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
