@@ -42,4 +42,9 @@ clean:
 	rm -f $(CSRC)/librt_hip.so $(HOST)/librt_host.so $(HOST)/rt_main
 	$(MAKE) -C oracle clean
 
-.PHONY: all device host oracle clean
+.PHONY: all device host oracle clean stamps
+
+# Diagnostic build with per-phase cycle stamps in the kernels (never loaded by default; RT_HIP_LIB selects it).
+stamps: $(CSRC)/librt_hip_stamps.so
+$(CSRC)/librt_hip_stamps.so: $(HIP_SOURCES) $(HIP_HEADERS)
+	$(HIPCC) $(HIPFLAGS) -DRT_STAMPS $(HIP_SOURCES) -o $@

@@ -216,6 +216,10 @@ int rt_set_profiling(rt_ctx *ctx, int enabled);
 /* Sum of stage durations in milliseconds and number of timed steps since profiling was enabled. */
 int rt_get_stage_times(rt_ctx *ctx, double ms[RT_STAGE_COUNT], uint64_t *steps);
 
+/* Diagnostic builds of the library (-DRT_STAMPS) sum shader-clock cycles per kernel phase over all
+ * waves; this reads (and optionally clears) those eight sums.  All zero in the shipped library. */
+int rt_debug_stamps(rt_ctx *ctx, uint64_t dst[8], int reset);
+
 /* The hipStream_t of the context, as an opaque pointer. */
 void *rt_stream(rt_ctx *ctx);
 

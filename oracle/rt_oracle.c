@@ -45,6 +45,7 @@ struct orc_ctx {
     rt_hit_record *hits;
     rt_counters counters;
     orc_work work;
+    uint64_t hit_hist[RT_MAX_HITS + 2]; /* visits by number of accepted boxes; last bin: more than 64 */
 };
 
 /* ------------------------------------------------------------------ vector helpers */
@@ -342,6 +343,7 @@ static void process_one(orc_ctx *c, uint32_t index, rt_index_pair *ray_index, or
 
     case RT_SH_AABB: { /* insert_hits, ray-tracer.cl:205-231 */
         const uint32_t n = aabb_shader(&cur, &grp->aabb, &ray->queue[0], new_hit, c->aabb);
+        if (c->threads <= 1) c->hit_hist[n]++;
         work->box_tests += grp->aabb.aabb_count;
         work->node_visits++;
         orc_sort_hits(new_hit, n);
@@ -789,6 +791,7 @@ rt_hit_record *orc_hits(orc_ctx *c) { return c->hits; }
 uint32_t orc_pool_size(orc_ctx *c) { return c->pool; }
 void orc_get_counters(orc_ctx *c, rt_counters *dst) { *dst = c->counters; }
 void orc_get_work(orc_ctx *c, orc_work *dst) { *dst = c->work; }
+void orc_get_hit_histogram(orc_ctx *c, uint64_t *dst) { memcpy(dst, c->hit_hist, sizeof(c->hit_hist)); }
 
 int orc_trace_closest(orc_ctx *c, const rt_ray *rays, uint32_t n_rays, rt_hit_record *hits)
 {

@@ -19,7 +19,7 @@ EXPORTS = (
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_init_frame", "rt_step", "rt_set_warp_width", "rt_sync",
     "rt_resolve_rgba8", "rt_read_area", "rt_current_ray", "rt_get_global", "rt_get_counters", "rt_sort_pairs",
     "rt_compact_groups", "rt_dump_state", "rt_read_hits", "rt_trace_closest", "rt_set_profiling",
-    "rt_get_stage_times", "rt_stream", "rt_status_string", "rt_last_error",
+    "rt_get_stage_times", "rt_debug_stamps", "rt_stream", "rt_status_string", "rt_last_error",
 )
 
 
@@ -42,9 +42,10 @@ def hip_lib():
     """Loads librt_hip.so; raises if it has not been built (no fallback path exists)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(HIP_LIB_PATH):
-            raise RuntimeError(f"{HIP_LIB_PATH} is missing: run `make device` (or __graft_entry__.build())")
-        lib = C.CDLL(HIP_LIB_PATH)
+        path = os.environ.get("RT_HIP_LIB", HIP_LIB_PATH)  # a diagnostic build of the same library, if given
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make device` (or __graft_entry__.build())")
+        lib = C.CDLL(path)
         vp, u32, sz, i = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
         sig = {
             "rt_create": (i, [C.POINTER(Config), C.POINTER(vp)]),
@@ -66,6 +67,7 @@ def hip_lib():
             "rt_trace_closest": (i, [vp, vp, u32, vp]),
             "rt_set_profiling": (i, [vp, i]),
             "rt_get_stage_times": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+            "rt_debug_stamps": (i, [vp, C.POINTER(C.c_uint64), i]),
             "rt_stream": (vp, [vp]),
             "rt_status_string": (C.c_char_p, [i]),
             "rt_last_error": (C.c_char_p, [vp]),
@@ -212,6 +214,11 @@ class RayTracer:
         steps = C.c_uint64()
         self._check(self.lib.rt_get_stage_times(self.h, ms, C.byref(steps)))
         return dict(zip(STAGE_NAMES, list(ms))), steps.value
+
+    def debug_stamps(self, reset=False):
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.rt_debug_stamps(self.h, out, int(reset)))
+        return list(out)
 
     def stream(self):
         return self.lib.rt_stream(self.h)

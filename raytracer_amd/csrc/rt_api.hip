@@ -23,11 +23,13 @@ struct rt_ctx {
     bool scene_ready = false, frame_ready = false;
 
     DevGlobal *glob = nullptr;
+    unsigned long long *counters = nullptr;
     float4 *area = nullptr;
     RaySlot *rays = nullptr;
     rt_index_pair *index = nullptr, *next = nullptr, *sorted = nullptr;
     rt_hit_record *hits = nullptr;
     rt_group_data *grp_data = nullptr;
+    SpillEntry *spill_list = nullptr;
     uchar4 *rgba = nullptr;
     SortWorkspace ws{};
 
@@ -88,9 +90,10 @@ LaunchCtx launch_ctx(const rt_ctx *c)
     LaunchCtx l{};
     l.stream = c->stream;
     l.scene = Scene{c->grp, c->mat, c->aabb, c->vtx, c->tri, c->tri_rec};
-    l.frame = Frame{c->glob, c->area, c->rays, c->index, c->next, c->hits};
+    l.frame = Frame{c->glob, c->counters, c->area, c->rays, c->index, c->next, c->hits};
     l.cam = c->cam;
     l.grp_data = c->grp_data;
+    l.spill_list = c->spill_list;
     l.pool = c->pool;
     l.area_size = c->area_size;
     l.group_count = c->group_count;
@@ -125,7 +128,7 @@ void expand_leaf(const rt_mesh_shader &mesh, const rt_vertex *vtx, const uint32_
         const float *a = vtx[mesh.vtx_offs + (word & 0x3FF)].pos;
         const float *b = vtx[mesh.vtx_offs + ((word >> 10) & 0x3FF)].pos;
         const float *c = vtx[mesh.vtx_offs + ((word >> 20) & 0x3FF)].pos;
-        TriRecord &r = out[mesh.tri_offs + i];
+        TriRecord &r = out[i];
         for (int k = 0; k < 3; k++) {
             r.r0[k] = a[k];
             r.p[k] = b[k] - a[k];
@@ -237,6 +240,8 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
     RT_HIP(c, hipSetDevice(cfg->device));
     RT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     RT_HIP(c, dev_alloc(c->glob, 1));
+    RT_HIP(c, dev_alloc(c->counters, size_t(kCounterShards) * kCounterKinds));
+    RT_HIP(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * kCounterShards * kCounterKinds, c->stream));
     RT_HIP(c, dev_alloc(c->area, c->area_size));
     RT_HIP(c, dev_alloc(c->rays, c->pool));
     RT_HIP(c, dev_alloc(c->index, c->pool));
@@ -245,6 +250,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
     RT_HIP(c, dev_alloc(c->ws.tmp, c->pool));
     RT_HIP(c, dev_alloc(c->hits, cfg->hit_capacity));
     RT_HIP(c, dev_alloc(c->rgba, c->area_size));
+    RT_HIP(c, dev_alloc(c->spill_list, c->pool / 64));
     c->ws.tiles = c->pool / RT_SORT_TILE;
     RT_HIP(c, dev_alloc(c->ws.counts, size_t(256) * c->ws.tiles));
     RT_HIP(c, dev_alloc(c->ws.totals, 256));
@@ -265,6 +271,7 @@ int rt_destroy(rt_ctx *c)
     for (hipEvent_t ev : c->spare) (void)hipEventDestroy(ev);
     free_scene(c);
     dev_free(c->glob);
+    dev_free(c->counters);
     dev_free(c->area);
     dev_free(c->rays);
     dev_free(c->index);
@@ -275,6 +282,7 @@ int rt_destroy(rt_ctx *c)
     dev_free(c->ws.totals);
     dev_free(c->hits);
     dev_free(c->rgba);
+    dev_free(c->spill_list);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
@@ -312,8 +320,20 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     };
     int rc = visit(data->cam.root_group, "camera root");
     if (rc) return rc;
-    std::vector<TriRecord> records(n_tri);
-    std::memset(records.data(), 0, records.size() * sizeof(TriRecord));
+    // Device copies of the lists the kernels scan, re-laid out: every box list starts on a multiple of
+    // four boxes and is filled up to one with boxes no ray can enter, every leaf's triangles start on a
+    // multiple of two and are filled up with null triangles no ray can hit, and both arrays end with
+    // spare entries.  The scan loops then need no tail handling and may read ahead past a list's end.
+    // The device group table carries the re-laid-out offsets.
+    std::vector<rt_group> dev_grp(grp, grp + n_groups);
+    std::vector<rt_aabb> dev_boxes;
+    std::vector<uint32_t> dev_tri;
+    std::vector<TriRecord> dev_rec;
+    rt_aabb never;
+    for (int k = 0; k < 3; k++) never.min[k] = never.max[k] = 1e30f;  // zero-size: exit parameter never exceeds entry
+    never.group_id = never.local_id = 0;
+    TriRecord null_tri;
+    std::memset(&null_tri, 0, sizeof(null_tri));  // zero normal: t is NaN, every comparison fails
     while (!work.empty()) {
         const uint32_t id = work.back();
         work.pop_back();
@@ -330,6 +350,9 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
                 if ((s.flags & RT_F_LOCAL0) && b.local_id >= n_mat)
                     return fail(c, RT_ERR_INVALID_VALUE, "box %u: instance %u of %zu matrices", s.aabb_offs + i, b.local_id, n_mat);
             }
+            dev_grp[id & RT_GROUP_ID_MASK].aabb.aabb_offs = uint32_t(dev_boxes.size());
+            dev_boxes.insert(dev_boxes.end(), aabb + s.aabb_offs, aabb + s.aabb_offs + s.aabb_count);
+            while (dev_boxes.size() % 4) dev_boxes.push_back(never);
         } else {
             const rt_mesh_shader &s = g.mesh;
             if (uint64_t(s.tri_offs) + s.tri_count > n_tri)
@@ -342,9 +365,21 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
             }
             const uint32_t mid = s.material_id & RT_GROUP_ID_MASK;
             if (mid >= n_groups) return fail(c, RT_ERR_INVALID_VALUE, "group %u: material group %u of %zu", id & RT_GROUP_ID_MASK, mid, n_groups);
-            expand_leaf(s, vtx, tri, records.data());
+            const size_t at = dev_tri.size();
+            dev_grp[id & RT_GROUP_ID_MASK].mesh.tri_offs = uint32_t(at);
+            dev_tri.insert(dev_tri.end(), tri + s.tri_offs, tri + s.tri_offs + s.tri_count);
+            dev_rec.resize(at + s.tri_count);
+            expand_leaf(s, vtx, tri, dev_rec.data() + at);
+            if (dev_tri.size() % 2) {
+                dev_tri.push_back(0);
+                dev_rec.push_back(null_tri);
+            }
         }
     }
+    dev_boxes.insert(dev_boxes.end(), 8, never);
+    dev_tri.insert(dev_tri.end(), 6, 0u);
+    dev_rec.insert(dev_rec.end(), 6, null_tri);
+    if (dev_boxes.size() > 0x7FFFFFFFu || dev_tri.size() > 0x7FFFFFFFu) return fail(c, RT_ERR_UNSUPPORTED, "scene too large");
     if (((data->cam.root_group >> RT_GROUP_TR_SHIFT) & RT_GROUP_TR_MASK) == RT_TR_ORTHO && data->cam.root_local >= n_mat)
         return fail(c, RT_ERR_INVALID_VALUE, "camera root instance %u of %zu matrices", data->cam.root_local, n_mat);
 
@@ -355,19 +390,19 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     c->cam = data->cam;
     RT_HIP(c, dev_alloc(c->grp, G));
     RT_HIP(c, dev_alloc(c->mat, n_mat));
-    RT_HIP(c, dev_alloc(c->aabb, n_aabb));
+    RT_HIP(c, dev_alloc(c->aabb, dev_boxes.size()));
     RT_HIP(c, dev_alloc(c->vtx, n_vtx));
-    RT_HIP(c, dev_alloc(c->tri, n_tri));
-    RT_HIP(c, dev_alloc(c->tri_rec, n_tri));
+    RT_HIP(c, dev_alloc(c->tri, dev_tri.size()));
+    RT_HIP(c, dev_alloc(c->tri_rec, dev_rec.size()));
     RT_HIP(c, dev_alloc(c->grp_data, G));
     RT_HIP(c, hipMemset(c->grp, 0, sizeof(rt_group) * size_t(G)));
     RT_HIP(c, hipMemset(c->grp_data, 0, sizeof(rt_group_data) * size_t(G)));
-    RT_HIP(c, hipMemcpy(c->grp, grp, sizeof(rt_group) * n_groups, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->grp, dev_grp.data(), sizeof(rt_group) * n_groups, hipMemcpyHostToDevice));
     if (n_mat) RT_HIP(c, hipMemcpy(c->mat, mat, sizeof(rt_matrix) * n_mat, hipMemcpyHostToDevice));
-    if (n_aabb) RT_HIP(c, hipMemcpy(c->aabb, aabb, sizeof(rt_aabb) * n_aabb, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->aabb, dev_boxes.data(), sizeof(rt_aabb) * dev_boxes.size(), hipMemcpyHostToDevice));
     if (n_vtx) RT_HIP(c, hipMemcpy(c->vtx, vtx, sizeof(rt_vertex) * n_vtx, hipMemcpyHostToDevice));
-    if (n_tri) RT_HIP(c, hipMemcpy(c->tri, tri, sizeof(uint32_t) * n_tri, hipMemcpyHostToDevice));
-    if (n_tri) RT_HIP(c, hipMemcpy(c->tri_rec, records.data(), sizeof(TriRecord) * n_tri, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->tri, dev_tri.data(), sizeof(uint32_t) * dev_tri.size(), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->tri_rec, dev_rec.data(), sizeof(TriRecord) * dev_rec.size(), hipMemcpyHostToDevice));
 
     DevGlobal init;
     std::memset(&init, 0, sizeof(init));
@@ -388,8 +423,7 @@ int rt_init_frame(rt_ctx *c)
     if (!c) return RT_ERR_INVALID_VALUE;
     if (!c->scene_ready) return fail(c, RT_ERR_NOT_READY, "rt_init_frame before rt_upload_scene");
     RT_HIP(c, hipSetDevice(c->cfg.device));
-    RT_HIP(c, hipMemsetAsync(reinterpret_cast<char *>(c->glob) + offsetof(DevGlobal, primary_spawned), 0,
-                             4 * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * kCounterShards * kCounterKinds, c->stream));
     launch_init_frame(launch_ctx(c));
     c->steps = 0;
     c->frame_ready = true;
@@ -464,17 +498,32 @@ int rt_current_ray(rt_ctx *c, uint32_t *pixel_offset)
     return RT_OK;
 }
 
+namespace {
+
+int read_counters(rt_ctx *c, unsigned long long sums[kCounterKinds], bool reset)
+{
+    std::vector<unsigned long long> shards(size_t(kCounterShards) * kCounterKinds);
+    RT_HIP(c, hipMemcpyAsync(shards.data(), c->counters, shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (reset) RT_HIP(c, hipMemsetAsync(c->counters, 0, shards.size() * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t k = 0; k < kCounterKinds; k++) sums[k] = 0;
+    for (size_t i = 0; i < shards.size(); i++) sums[i % kCounterKinds] += shards[i];
+    return RT_OK;
+}
+
+}  // namespace
+
 int rt_get_counters(rt_ctx *c, rt_counters *dst)
 {
     if (!c || !dst) return RT_ERR_INVALID_VALUE;
-    DevGlobal g;
-    RT_HIP(c, hipMemcpyAsync(&g, c->glob, sizeof(g), hipMemcpyDeviceToHost, c->stream));
-    RT_HIP(c, hipStreamSynchronize(c->stream));
-    dst->primary_spawned = g.primary_spawned;
-    dst->shadow_spawned = g.shadow_spawned;
+    unsigned long long sums[kCounterKinds];
+    const int rc = read_counters(c, sums, false);
+    if (rc) return rc;
+    dst->primary_spawned = sums[kPrimarySpawned];
+    dst->shadow_spawned = sums[kShadowSpawned];
     dst->steps = c->steps;
-    dst->box_tests = g.box_tests;
-    dst->tri_tests = g.tri_tests;
+    dst->box_tests = sums[kBoxTests];
+    dst->tri_tests = sums[kTriTests];
     return RT_OK;
 }
 
@@ -652,6 +701,23 @@ int rt_get_stage_times(rt_ctx *c, double ms[RT_STAGE_COUNT], uint64_t *steps)
     if (rc) return rc;
     for (int s = 0; s < RT_STAGE_COUNT; s++) ms[s] = c->stage_ms[s];
     if (steps) *steps = c->timed_steps;
+    return RT_OK;
+}
+
+int rt_debug_stamps(rt_ctx *c, uint64_t dst[8], int reset)
+{
+    if (!c || !dst) return RT_ERR_INVALID_VALUE;
+    unsigned long long sums[kCounterKinds];
+    const int rc = read_counters(c, sums, false);
+    if (rc) return rc;
+    for (int k = 0; k < 8; k++) dst[k] = k < 4 ? sums[4 + k] : 0;
+    if (reset) {
+        // only the stamp half of every shard is cleared; the event counters keep running
+        std::vector<unsigned long long> zero(4, 0);
+        for (uint32_t s = 0; s < kCounterShards; s++)
+            RT_HIP(c, hipMemcpyAsync(c->counters + size_t(s) * kCounterKinds + 4, zero.data(), 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return RT_OK;
 }
 

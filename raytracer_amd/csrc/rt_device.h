@@ -52,9 +52,14 @@ static_assert(sizeof(TriRecord) == 48, "triangle record must be 48 bytes");
 struct alignas(16) DevGlobal {
     rt_global_data g;
     uint32_t warp_width, sample_limit, hit_capacity, row_offset;
-    uint32_t mode, sort_count, pad0, pad1;  // sort_count: element count for stand-alone sort calls
-    unsigned long long primary_spawned, shadow_spawned;
-    unsigned long long box_tests, tri_tests;  // boxes / triangles scanned, summed over rays (work counters)
+    uint32_t mode, sort_count, spill_count, pad1;  // sort_count: element count for stand-alone sort calls;
+                                                    // spill_count: rays queued for the large box-visit kernel
+};
+
+// Hand-over of one wave's unfinished box visits from the main kernel to the large-list kernel.
+struct SpillEntry {
+    unsigned long long lanes;  // which of the 64 positions starting at `first`
+    uint32_t first, pad;
 };
 
 struct Scene {
@@ -66,8 +71,16 @@ struct Scene {
     const TriRecord *tri_rec;
 };
 
+// Event counters are sharded: every wave adds to the shard of its workgroup, one 64-byte line each, and
+// the host sums the shards.  Thousands of waves adding to ONE word serialise at about 12 ns per atomic,
+// which is as long as a whole kernel here, and every wave would sit out its own atomic at its next
+// wait for a load (vmcnt counts atomics too).
+constexpr uint32_t kCounterShards = 1024;
+enum Counter : uint32_t { kPrimarySpawned = 0, kShadowSpawned = 1, kBoxTests = 2, kTriTests = 3, kCounterKinds = 8 };
+
 struct Frame {
     DevGlobal *glob;
+    unsigned long long *counters;  // [kCounterShards][kCounterKinds]
     float4 *area;
     RaySlot *rays;
     rt_index_pair *index;        // (group key, slot) in processing order, input of a step
@@ -120,9 +133,27 @@ __device__ __forceinline__ ConstPtr<T> const_ptr(const void *p)
 // Built-in vector types: unlike HIP's float4/uint4 structs they can be loaded through ConstPtr.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// Phase timing for diagnostic builds: RT_STAMP(t) reads the shader clock into t, RT_STAMP_ADD adds a
+// difference to counter 4 + (slot & 3) of the workgroup's shard once per wave.  Both compile to nothing in the shipped library.
+#ifdef RT_STAMPS
+#define RT_STAMP(var) \
+    unsigned long long var; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define RT_STAMP_ADD(frame, slot, from, to) \
+    do { \
+        const unsigned long long m_ = __ballot(true); \
+        if (lane_id() == (uint32_t)(__ffsll((long long)m_) - 1)) \
+            atomicAdd(&(frame).counters[(blockIdx.x % kCounterShards) * kCounterKinds + 4 + ((slot) & 3)], (to) - (from)); \
+    } while (0)
+#else
+#define RT_STAMP(var)
+#define RT_STAMP_ADD(frame, slot, from, to)
+#endif
 
 // The value of v in the first active lane, in a scalar register.  Call it where all active lanes are
 // known to hold the same v: written as an asm statement so that the optimiser can neither fold it into

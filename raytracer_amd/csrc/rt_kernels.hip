@@ -94,12 +94,13 @@ __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlob
     return reset_ray(ray, cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
 }
 
-// One atomic per wave for a per-lane event count (each counted lane adds `weight`, wave-uniform).
-__device__ __forceinline__ void count_lanes(unsigned long long *counter, bool flag, uint32_t weight = 1)
+// One atomic per wave for a per-lane event count (each counted lane adds `weight`, wave-uniform), to
+// the counter shard of this workgroup.
+__device__ __forceinline__ void count_lanes(const Frame &frame, Counter which, bool flag, uint32_t weight = 1)
 {
     const unsigned long long mask = __ballot(flag);
     if (flag && lane_id() == (uint32_t)(__ffsll((long long)mask) - 1))
-        atomicAdd(counter, (unsigned long long)__popcll(mask) * weight);
+        atomicAdd(&frame.counters[(blockIdx.x % kCounterShards) * kCounterKinds + which], (unsigned long long)__popcll(mask) * weight);
 }
 
 // ---------------------------------------------------------------- frame kernels
@@ -121,11 +122,12 @@ __global__ void k_init_rays(ProcessArgs a, uint32_t pool)
     bool started;
     const uint32_t key = init_ray(a.cam, a.frame.glob, &a.frame.rays[index], a.frame.hits, a.group_count, index, started);
     a.frame.index[index] = rt_index_pair{key, index};
-    count_lanes(&a.frame.glob->primary_spawned, started);
+    count_lanes(a.frame, kPrimarySpawned, started);
     if (index) return;
     a.frame.glob->g.pixel_offset = pool;
     a.frame.glob->g.pixel_count = 0;
     a.frame.glob->g.ray_count = pool;
+    a.frame.glob->spill_count = 0;
 }
 
 // Loads caller rays as samples 0..n_rays-1 (rt_trace_closest); the remaining slots are parked.
@@ -148,6 +150,7 @@ __global__ void k_load_rays(ProcessArgs a, uint32_t pool, const rt_ray *rays, ui
     a.frame.glob->g.pixel_offset = pool;
     a.frame.glob->g.pixel_count = 0;
     a.frame.glob->g.ray_count = pool;
+    a.frame.glob->spill_count = 0;
 }
 
 // update_image (ray-tracer.cl:305-309), writing RGBA8 the way write_imagef converts to UNORM8.
@@ -177,10 +180,10 @@ struct LocalRay {
     V3 m0, m1, m2;  // columns of the instance rotation (identity for world-space groups)
 };
 
-__device__ __forceinline__ LocalRay make_local(uint32_t g, const RaySlot *ray, uint32_t local0, const rt_matrix *mat_list)
+__device__ __forceinline__ LocalRay make_local(uint32_t g, const float4 sm, const float4 dm, uint32_t local0,
+                                               const rt_matrix *mat_list)
 {
     LocalRay r;
-    const float4 sm = ray->start_min, dm = ray->dir_max;
     r.start = xyz(sm);
     r.dir = xyz(dm);
     r.tmin = sm.w;
@@ -297,64 +300,119 @@ __device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color)
 __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const ProcessArgs &a)
 {
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // vtx_offs, tri_offs, tri_count, material_id
-    const uint32_t queue_len = ray->queue_len;
-    const RayHit head = ray->queue[0];
-    const LocalRay lr = make_local(g, ray, head.local0, a.scene.mat);
+    // The slot's first 128-byte line (meta, ray, queue[0..4]) is requested at once and the rest of the
+    // queue if it is that long, so that the triangle scan covers the latency.
+    const uint4 meta = *reinterpret_cast<const uint4 *>(ray);  // pixel, type, material_id, queue_len
+    const float4 sm = ray->start_min, dm = ray->dir_max;
+    const uint32_t queue_len = meta.w;
+    RayHit q[RT_MAX_QUEUE_LEN];
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = ray->queue[i];
+#pragma unroll
+    for (int i = 5; i < RT_MAX_QUEUE_LEN; i++) {
+        q[i] = RayHit{0.0f, 0u, 0u, 0u};
+        if ((uint32_t)i < queue_len) q[i] = ray->queue[i];
+    }
+    const RayHit head = q[0];
+    const LocalRay lr = make_local(g, sm, dm, head.local0, a.scene.mat);
 
-    count_lanes(&a.frame.glob->tri_tests, true, grp.z);
-    ConstPtr<f32x4> rec = const_ptr<f32x4>(a.scene.tri_rec + grp.y);  // three 16-byte words per triangle
+    count_lanes(a.frame, kTriTests, true, grp.z);
+    // Triangle scan.  Leaf payload is wave-uniform: 48 bytes per triangle (r0, p, q, n) through the
+    // scalar cache, two triangles (three 32-byte loads) at a time; the device copy of a leaf's list
+    // starts on an even index, is filled up to an even count with null triangles and is followed by
+    // readable entries, so the next pair is always requested before the current pair is tested.
+    ConstPtr<f32x8> rec = const_ptr<f32x8>(a.scene.tri_rec + grp.y);
     float best = lr.tmax, hit_u = 0, hit_v = 0;
     uint32_t hit_index = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < grp.z; i++) {
-        const f32x4 w0 = rec[3 * i], w1 = rec[3 * i + 1], w2 = rec[3 * i + 2];  // r0.xyz p.x | p.yz q.xy | q.z n.xyz
-        const V3 p = v3(w0.w, w1.x, w1.y), q = v3(w1.z, w1.w, w2.x), n = v3(w2.y, w2.z, w2.w);
-        const V3 r = v3(w0.x, w0.y, w0.z) - lr.start;
+    const uint32_t count = grp.z;
+    auto test_tri = [&](V3 r0, V3 p, V3 q_, V3 n, uint32_t i) {
+        const V3 r = r0 - lr.start;
         float w = dot(lr.dir, n);
         w = 1 / w;
         const float tt = dot(r, n) * w;
-        if (!(tt > lr.tmin && tt < best)) continue;
+        if (!(tt > lr.tmin && tt < best)) return;
         const V3 dr = cross(lr.dir, r);
-        const float u = -dot(q, dr) * w, v = dot(p, dr) * w;
-        if (!(u >= 0 && v >= 0 && u + v <= 1)) continue;
+        const float u = -dot(q_, dr) * w, v = dot(p, dr) * w;
+        if (!(u >= 0 && v >= 0 && u + v <= 1)) return;
         best = tt;
         hit_u = u;
         hit_v = v;
         hit_index = i;
+    };
+    auto test_two = [&](const f32x8 x, const f32x8 y, const f32x8 z, uint32_t i) {
+        test_tri(v3(x.s0, x.s1, x.s2), v3(x.s3, x.s4, x.s5), v3(x.s6, x.s7, y.s0), v3(y.s1, y.s2, y.s3), i);
+        test_tri(v3(y.s4, y.s5, y.s6), v3(y.s7, z.s0, z.s1), v3(z.s2, z.s3, z.s4), v3(z.s5, z.s6, z.s7), i + 1);
+    };
+    if (count) {
+        f32x8 a0 = rec[0], a1 = rec[1], a2 = rec[2];
+        for (uint32_t i = 0;; i += 4) {
+            const uint32_t at = 3 * (i / 2);
+            const f32x8 b0 = rec[at + 3], b1 = rec[at + 4], b2 = rec[at + 5];
+            test_two(a0, a1, a2, i);
+            if (i + 2 >= count) break;
+            a0 = rec[at + 6];
+            a1 = rec[at + 7];
+            a2 = rec[at + 8];
+            test_two(b0, b1, b2, i + 2);
+            if (i + 4 >= count) break;
+        }
     }
 
-    OldQueue old;
-    load_pending(old, ray, queue_len);
-    uint32_t len = queue_len - 1;
-    if (hit_index == 0xFFFFFFFFu)  // miss: pop the head (ray-tracer.cl:154-165)
-        return store_shifted(ray, old, len, head.pos, ray->material_id);
-
-    // insert_stop (ray-tracer.cl:173-203)
-    uint32_t end_group;
-    if (ray->type == RT_RAY_SHADOW) {
-        unsafeAtomicAdd(reinterpret_cast<float *>(&a.frame.area[ray->pixel]) + 3, ray->weight.w);
-        end_group = RT_SPAWN_GROUP;
-    } else {
-        const uint32_t word = a.scene.tri[grp.y + hit_index];
-        const rt_vertex *vtx = a.scene.vtx + grp.x;
-        const float4 n0 = *reinterpret_cast<const float4 *>(vtx[word & 0x3FF].norm);
-        const float4 n1 = *reinterpret_cast<const float4 *>(vtx[(word >> 10) & 0x3FF].norm);
-        const float4 n2 = *reinterpret_cast<const float4 *>(vtx[(word >> 20) & 0x3FF].norm);
-        const V3 nn = (xyz(n0) * (1 - hit_u - hit_v) + xyz(n1) * hit_u) + xyz(n2) * hit_v;
-        const V3 nw = (lr.m0 * nn.x + lr.m1 * nn.y) + lr.m2 * nn.z;
-        ray->norm = make_float4(nw.x, nw.y, nw.z, 0.0f);
-        ray->dir_max.w = best;
-        ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
-        ray->hit_tri = hit_index;
-        const uint32_t sid = ray->sample_id;
-        if (sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
-        end_group = grp.w;
+    // Miss: pop the head (ray-tracer.cl:154-165).  Hit: insert_stop (ray-tracer.cl:173-203).  What a
+    // hit still needs from memory (shading normal, sample id, or the shadow weight) is loaded before
+    // the first store of this visit.
+    const bool hit = hit_index != 0xFFFFFFFFu, shadow = meta.y == RT_RAY_SHADOW;
+    uint32_t len = queue_len - 1, end_group = meta.z, sid = 0xFFFFFFFFu;
+    float shadow_weight = 0;
+    V3 nw = v3(0, 0, 0);
+    if (hit) {
+        if (shadow) {
+            shadow_weight = ray->weight.w;
+            end_group = RT_SPAWN_GROUP;
+        } else {
+            const uint32_t word = a.scene.tri[grp.y + hit_index];
+            sid = ray->sample_id;
+            const rt_vertex *vtx = a.scene.vtx + grp.x;
+            const float4 n0 = *reinterpret_cast<const float4 *>(vtx[word & 0x3FF].norm);
+            const float4 n1 = *reinterpret_cast<const float4 *>(vtx[(word >> 10) & 0x3FF].norm);
+            const float4 n2 = *reinterpret_cast<const float4 *>(vtx[(word >> 20) & 0x3FF].norm);
+            const V3 nn = (xyz(n0) * (1 - hit_u - hit_v) + xyz(n1) * hit_u) + xyz(n2) * hit_v;
+            nw = (lr.m0 * nn.x + lr.m1 * nn.y) + lr.m2 * nn.z;
+            end_group = grp.w;
+        }
+        // pending nodes that start at or beyond the hit are dropped, and everything after them
+#pragma unroll
+        for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
+            if ((uint32_t)i < len && q[i + 1].pos >= best) len = i;
     }
-    // pending nodes that start at or beyond the hit are dropped, and everything after them
+
+    if (hit) {
+        if (shadow) {
+            unsafeAtomicAdd(reinterpret_cast<float *>(&a.frame.area[meta.x]) + 3, shadow_weight);
+        } else {
+            ray->norm = make_float4(nw.x, nw.y, nw.z, 0.0f);
+            ray->dir_max.w = best;
+            ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
+            ray->hit_tri = hit_index;
+            if (sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
+        }
+        ray->material_id = end_group;
+    }
+    // save_queue + copy_queue (ray-tracer.cl:157-168, 195-203)
 #pragma unroll
     for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
-        if ((uint32_t)i < len && old.e[i + 1].pos >= best) len = i;
-    ray->material_id = end_group;
-    return store_shifted(ray, old, len, head.pos, end_group);
+        if ((uint32_t)i < len) ray->queue[i] = q[i + 1];
+    if (len) {
+        ray->queue_len = len;
+        ray->start_min.w = head.pos;
+        return q[1].group_id;
+    }
+    // Empty: the head becomes the ray's end group; queue[0].pos keeps its value (the reference leaves
+    // it indeterminate, ray-tracer.cl:164,201), queue_len and t_min are left alone.
+    ray->queue[0].group_id = end_group;
+    ray->queue[0].local0 = 0;
+    ray->queue[0].local1 = 0;
+    return end_group;
 }
 
 // ---------------------------------------------------------------- process, everything but box groups
@@ -386,7 +444,7 @@ __global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t po
         case RT_SH_SPAWN: {
             bool started;
             new_key = init_ray(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
-            count_lanes(&a.frame.glob->primary_spawned, started);
+            count_lanes(a.frame, kPrimarySpawned, started);
             break;
         }
         case RT_SH_SKY:
@@ -404,7 +462,7 @@ __global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t po
             }
             const f32x4 color = *const_ptr<f32x4>(a.scene.grp + (g & kIdMask));
             new_key = mat_shader(ray, make_float4(color.x, color.y, color.z, color.w));
-            count_lanes(&a.frame.glob->shadow_spawned, true);
+            count_lanes(a.frame, kShadowSpawned, true);
             break;
         }
         case RT_SH_MESH:
@@ -425,18 +483,219 @@ __global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t po
 
 // ---------------------------------------------------------------- process, box groups
 // aabb_shader (shader.cl:76-101) + insert_hits (ray-tracer.cl:90-117, 205-231)
+//
+// Two kernels share one body.  More than 16 accepted boxes in a visit are rare (3 visits in 10,000 on
+// the benchmark scene, 5 in a million more than 24), so the main kernel keeps 24 candidates per lane in LDS (30 KB per block:
+// occupancy is then 5 waves per SIMD instead of 2); a lane that accepts a 25th box leaves its ray
+// untouched and queues it for the second kernel, which has room for the reference's 64 candidates.
 
-constexpr int kAabbThreads = 256;
+constexpr int kAabbThreads = 256;  // main kernel
+constexpr int kAabbCap = 24;
+constexpr int kBigThreads = 64;    // overflow kernel: one wave per block
+constexpr int kBigBlocks = 256;
 
-__global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a)
+// One box against one ray: entry and exit parameter of the slab test (shader.cl:86-91).
+__device__ __forceinline__ bool box_test(const f32x8 b, const LocalRay &lr, const V3 inv_dir, float &t_entry)
 {
-    // Candidate boxes of each lane's visit: entry position and index of the box in the group's list.
-    __shared__ float s_pos[RT_MAX_HITS][kAabbThreads];
-    __shared__ uint8_t s_idx[RT_MAX_HITS][kAabbThreads];
+    const V3 pos1 = (v3(b.s0, b.s1, b.s2) - lr.start) * inv_dir;
+    const V3 pos2 = (v3(b.s4, b.s5, b.s6) - lr.start) * inv_dir;
+    const float t_min = fmaxf(fmaxf(fminf(pos1.x, pos2.x), fminf(pos1.y, pos2.y)), fminf(pos1.z, pos2.z));
+    const float t_max = fminf(fminf(fmaxf(pos1.x, pos2.x), fmaxf(pos1.y, pos2.y)), fmaxf(pos1.z, pos2.z));
+    t_entry = fmaxf(t_min, lr.tmin);
+    return t_max > t_min && t_max > lr.tmin && t_min < lr.tmax;
+}
+
+// One visit of box group g (wave-uniform) by this lane's ray.  CAP = candidates kept per lane; with
+// BIG the reference's limit applies (a 65th candidate empties the list, shader.cl:93), otherwise a
+// lane that needs more than CAP returns false without having changed its ray.
+template <int CAP, int THREADS, bool BIG>
+__device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
+                                           uint8_t (*s_idx)[THREADS], uint32_t tid, uint32_t &new_key)
+{
+    RT_STAMP(t_start);
+    const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
+    const uint32_t count = grp.y;
+    // Everything this visit needs from the ray slot is requested now, so that the box scan covers the
+    // latency: the slot's first 128-byte line (meta, ray, queue[0..4]) without conditions, the rest
+    // of the queue only if it is that long.  No load is issued once the stores of the merge begin.
+    const uint4 meta = *reinterpret_cast<const uint4 *>(ray);  // pixel, type, material_id, queue_len
+    const float4 sm = ray->start_min, dm = ray->dir_max;
+    const uint32_t old_len = meta.w;
+    RayHit q[RT_MAX_QUEUE_LEN];
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = ray->queue[i];
+#pragma unroll
+    for (int i = 5; i < RT_MAX_QUEUE_LEN; i++) {
+        q[i] = RayHit{0.0f, 0u, 0u, 0u};
+        if ((uint32_t)i < old_len) q[i] = ray->queue[i];
+    }
+    const RayHit head = q[0];
+    const LocalRay lr = make_local(g, sm, dm, head.local0, a.scene.mat);
+    const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
+    if (!BIG) count_lanes(a.frame, kBoxTests, true, count);
+
+    // Box scan.  The list is wave-uniform and comes through the scalar cache, 64 bytes (two boxes) per
+    // load; the device copy of a list starts on a 128-byte boundary, is filled up to a multiple of
+    // four with boxes no ray can enter and is followed by readable entries, so four boxes are tested
+    // per half iteration without tail handling, while the loads for the next four are in flight.
+    ConstPtr<f32x16> pair = const_ptr<f32x16>(a.scene.aabb + grp.x);  // per box: min.xyz, group id, max.xyz, local id
+    asm volatile("" ::"v"(inv_dir.x), "v"(inv_dir.y), "v"(inv_dir.z), "v"(lr.start.x));
+    RT_STAMP(t_loaded);
+    uint32_t n = 0;
+    bool spill = false;
+    auto test_pair = [&](const f32x16 p, uint32_t i) {
+        float t;
+        const bool hit0 = box_test(p.lo, lr, inv_dir, t);
+        if (hit0) {
+            if (n < CAP) {
+                s_pos[n][tid] = t;
+                s_idx[n][tid] = (uint8_t)i;
+                n++;
+            } else {
+                spill = true;
+            }
+        }
+        const bool hit1 = box_test(p.hi, lr, inv_dir, t);
+        if (hit1) {
+            if (n < CAP) {
+                s_pos[n][tid] = t;
+                s_idx[n][tid] = (uint8_t)(i + 1);
+                n++;
+            } else {
+                spill = true;
+            }
+        }
+    };
+    if (count) {
+        f32x16 a0 = pair[0], a1 = pair[1];
+        for (uint32_t i = 0;; i += 8) {
+            const f32x16 b0 = pair[i / 2 + 2], b1 = pair[i / 2 + 3];
+            test_pair(a0, i);
+            test_pair(a1, i + 2);
+            if (i + 4 >= count) break;
+            a0 = pair[i / 2 + 4];
+            a1 = pair[i / 2 + 5];
+            test_pair(b0, i + 4);
+            test_pair(b1, i + 6);
+            if (i + 8 >= count) break;
+        }
+    }
+    RT_STAMP(t_scanned);
+    RT_STAMP_ADD(a.frame, 0, t_start, t_loaded);
+    RT_STAMP_ADD(a.frame, 1, t_loaded, t_scanned);
+    if (spill) {
+        if (!BIG) return false;
+        n = 0;  // more than 64 candidates: the reference gives up on the whole node
+    }
+
+    // sort_hits (ray-tracer.cl:90-117): the reference's compare-exchange network, run with
+    // wave-uniform (i, j) so every LDS access has a uniform row; lanes with fewer entries idle.
+    const uint32_t n_max = wave_max_upto127(n);
+    auto exchange = [&](uint32_t j, uint32_t i) {
+        if (i < n) {
+            const float pj = s_pos[j][tid], pi = s_pos[i][tid];
+            if (pj > pi) {
+                const uint8_t ij = s_idx[j][tid], ii = s_idx[i][tid];
+                s_pos[j][tid] = pi;  s_pos[i][tid] = pj;
+                s_idx[j][tid] = ii;  s_idx[i][tid] = ij;
+            }
+        }
+    };
+    for (uint32_t base = 1; base < n_max; base *= 2) {
+        for (uint32_t i = base; i < n_max; i++)
+            if (i & base) exchange(i - 2 * (i & (base - 1)) - 1, i);
+        for (uint32_t offs = base / 2; offs; offs /= 2)
+            for (uint32_t i = offs; i < n_max; i++)
+                if (i & offs) exchange(i - offs, i);
+    }
+
+    RT_STAMP(t_sorted);
+    RT_STAMP_ADD(a.frame, 2, t_scanned, t_sorted);
+    // insert_hits (ray-tracer.cl:205-231): merge the sorted candidates with the pending entries, old
+    // entry first on equal position, at most 8 entries, the 8th turned into a root restart.  Both
+    // lists are sorted, so every entry's place in the merged queue is a count: a pending entry i goes
+    // behind the earlier pending entries and the candidates strictly before it, a candidate j behind
+    // the earlier candidates and the pending entries not after it.  Only the first 8 candidates can
+    // land inside the queue.  Their child ids are fetched together, then every surviving entry is
+    // stored to its place from registers -- independent stores, no load in between.
+    const bool take0 = (grp.z & RT_F_LOCAL0) != 0, take1 = (grp.z & RT_F_LOCAL1) != 0;
+    const rt_aabb *list = a.scene.aabb + grp.x;
+    float cand_pos[RT_MAX_QUEUE_LEN];
+    uint32_t cand_group[RT_MAX_QUEUE_LEN], cand_local[RT_MAX_QUEUE_LEN];
+#pragma unroll
+    for (int j = 0; j < RT_MAX_QUEUE_LEN; j++) {
+        cand_pos[j] = INFINITY;
+        cand_group[j] = cand_local[j] = 0;
+        if ((uint32_t)j < n) {
+            const uint32_t bi = s_idx[j][tid];
+            cand_pos[j] = s_pos[j][tid];
+            cand_group[j] = list[bi].group_id;
+            cand_local[j] = list[bi].local_id;
+        }
+    }
+    const uint32_t merged = old_len - 1 + n;
+    const bool overflow = merged >= RT_MAX_QUEUE_LEN;
+    const uint32_t k = overflow ? RT_MAX_QUEUE_LEN : merged;
+    RayHit root = RayHit{0.0f, 0u, 0u, 0u};
+    if (overflow) root = ray->root;  // ray-tracer.cl:228-231: the 8th entry keeps its position, restarts from the root later
+    uint32_t first_group = 0;
+    auto place = [&](uint32_t at, RayHit e) {
+        if (at >= RT_MAX_QUEUE_LEN) return;
+        if (at == RT_MAX_QUEUE_LEN - 1) {
+            e.group_id = root.group_id;
+            e.local0 = root.local0;
+            e.local1 = root.local1;
+        }
+        if (at == 0) first_group = e.group_id;
+#ifndef RT_ABLATE_STORES
+        ray->queue[at] = e;
+#else
+        asm volatile("" ::"v"(e.pos), "v"(e.group_id), "v"(e.local0), "v"(e.local1), "v"(at));
+#endif
+    };
+#pragma unroll
+    for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
+        if ((uint32_t)i < old_len) {
+            uint32_t at = i - 1;
+#pragma unroll
+            for (int j = 0; j < RT_MAX_QUEUE_LEN; j++) at += cand_pos[j] < q[i].pos ? 1u : 0u;
+            place(at, q[i]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RT_MAX_QUEUE_LEN; j++) {
+        if ((uint32_t)j < n) {
+            uint32_t at = j;
+#pragma unroll
+            for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) at += ((uint32_t)i < old_len && !(cand_pos[j] < q[i].pos)) ? 1u : 0u;
+            place(at, RayHit{cand_pos[j], cand_group[j], take0 ? cand_local[j] : head.local0, take1 ? cand_local[j] : head.local1});
+        }
+    }
+    // save_queue (ray-tracer.cl:157-165)
+    if (k) {
+        ray->queue_len = k;
+        ray->start_min.w = head.pos;
+        new_key = first_group;
+    } else {
+        const uint32_t end_group = meta.z;
+        ray->queue[0].group_id = end_group;
+        ray->queue[0].local0 = 0;
+        ray->queue[0].local1 = 0;
+        new_key = end_group;
+    }
+    RT_STAMP(t_merged);
+    RT_STAMP_ADD(a.frame, 3, t_sorted, t_merged);
+    return true;
+}
+
+__global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, SpillEntry *spill_list)
+{
+    __shared__ float s_pos[kAabbCap][kAabbThreads];
+    __shared__ uint8_t s_idx[kAabbCap][kAabbThreads];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t index = blockIdx.x * blockDim.x + tid;
-    const DevGlobal *glob = a.frame.glob;
+    DevGlobal *glob = a.frame.glob;
     if (index >= glob->g.ray_count) return;
     const rt_index_pair entry = a.frame.index[index];
     const uint32_t key = entry.key;
@@ -444,167 +703,108 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a)
     RaySlot *ray = &a.frame.rays[entry.slot];
 
     uint32_t new_key = key;
-    bool todo = true;
+    bool done = true, todo = true;
     while (todo) {
         if (key != __builtin_amdgcn_readfirstlane(key)) continue;
         todo = false;
         const uint32_t g = uniform_value(key);  // every lane still here holds the same key
-
-        const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
-        const uint32_t old_len = ray->queue_len;
-        const RayHit head = ray->queue[0];
-        const LocalRay lr = make_local(g, ray, head.local0, a.scene.mat);
-        const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
-
-        count_lanes(&a.frame.glob->box_tests, true, grp.y);
-        ConstPtr<f32x8> box = const_ptr<f32x8>(a.scene.aabb + grp.x);  // min.xyz, group id, max.xyz, local id
-        uint32_t n = 0;
-        bool too_many = false;
-        for (uint32_t i = 0; i < grp.y; i++) {
-            const f32x8 b = box[i];
-            const V3 pos1 = (v3(b.s0, b.s1, b.s2) - lr.start) * inv_dir;
-            const V3 pos2 = (v3(b.s4, b.s5, b.s6) - lr.start) * inv_dir;
-            const float t_min = fmaxf(fmaxf(fminf(pos1.x, pos2.x), fminf(pos1.y, pos2.y)), fminf(pos1.z, pos2.z));
-            const float t_max = fminf(fminf(fmaxf(pos1.x, pos2.x), fmaxf(pos1.y, pos2.y)), fmaxf(pos1.z, pos2.z));
-            if (!(t_max > t_min && t_max > lr.tmin && t_min < lr.tmax)) continue;
-            if (too_many) continue;
-            if (n >= RT_MAX_HITS) {  // the reference gives up on the whole node (shader.cl:93)
-                too_many = true;
-                continue;
-            }
-            s_pos[n][tid] = fmaxf(t_min, lr.tmin);
-            s_idx[n][tid] = (uint8_t)i;
-            n++;
-        }
-        if (too_many) n = 0;
-
-        // sort_hits (ray-tracer.cl:90-117): the reference's compare-exchange network, run with
-        // wave-uniform (i, j) so every LDS access has a uniform row; lanes with fewer entries idle.
-        const uint32_t n_max = wave_max_upto127(n);
-        for (uint32_t base = 1; base < n_max; base *= 2) {
-            for (uint32_t i = base; i < n_max; i++) {
-                if (!(i & base)) continue;
-                const uint32_t j = i - 2 * (i & (base - 1)) - 1;
-                if (i < n) {
-                    const float pj = s_pos[j][tid], pi = s_pos[i][tid];
-                    if (pj > pi) {
-                        const uint8_t ij = s_idx[j][tid], ii = s_idx[i][tid];
-                        s_pos[j][tid] = pi;  s_pos[i][tid] = pj;
-                        s_idx[j][tid] = ii;  s_idx[i][tid] = ij;
-                    }
-                }
-            }
-            for (uint32_t offs = base / 2; offs; offs /= 2)
-                for (uint32_t i = offs; i < n_max; i++) {
-                    if (!(i & offs)) continue;
-                    const uint32_t j = i - offs;
-                    if (i < n) {
-                        const float pj = s_pos[j][tid], pi = s_pos[i][tid];
-                        if (pj > pi) {
-                            const uint8_t ij = s_idx[j][tid], ii = s_idx[i][tid];
-                            s_pos[j][tid] = pi;  s_pos[i][tid] = pj;
-                            s_idx[j][tid] = ii;  s_idx[i][tid] = ij;
-                        }
-                    }
-                }
-        }
-
-        // insert_hits (ray-tracer.cl:205-231): merge the sorted candidates with the pending entries,
-        // old entry first on equal position, at most 8 entries, the 8th turned into a root restart.
-        OldQueue old;
-        load_pending(old, ray, old_len);
-        const bool take0 = (grp.z & RT_F_LOCAL0) != 0, take1 = (grp.z & RT_F_LOCAL1) != 0;
-        const rt_aabb *list = a.scene.aabb + grp.x;
-        uint32_t k = 0, next = 0, first_group = 0;
-        bool overflow = false;
-
-        auto emit_candidate = [&]() {
-            const uint32_t bi = s_idx[next][tid];
-            const uint32_t child = list[bi].group_id, child_local = list[bi].local_id;
-            ray->queue[k] = RayHit{s_pos[next][tid], child, take0 ? child_local : head.local0, take1 ? child_local : head.local1};
-            if (k == 0) first_group = child;
-            k++;
-            next++;
-            if (k == RT_MAX_QUEUE_LEN) overflow = true;
-        };
-
-#pragma unroll
-        for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
-            if ((uint32_t)i < old_len && !overflow) {
-                const float pos = old.e[i].pos;
-                while (!overflow && next < n && s_pos[next][tid] < pos) emit_candidate();
-                if (!overflow) {
-                    ray->queue[k] = old.e[i];
-                    if (k == 0) first_group = old.e[i].group_id;
-                    k++;
-                    if (k == RT_MAX_QUEUE_LEN) overflow = true;
-                }
-            }
-        }
-        while (!overflow && next < n) emit_candidate();
-        if (overflow) {  // ray-tracer.cl:228-231: keep the position, restart from the root later
-            const RayHit root = ray->root;
-            ray->queue[RT_MAX_QUEUE_LEN - 1].group_id = root.group_id;
-            ray->queue[RT_MAX_QUEUE_LEN - 1].local0 = root.local0;
-            ray->queue[RT_MAX_QUEUE_LEN - 1].local1 = root.local1;
-        }
-        // save_queue (ray-tracer.cl:157-165)
-        if (k) {
-            ray->queue_len = k;
-            ray->start_min.w = head.pos;
-            new_key = first_group;
-        } else {
-            const uint32_t end_group = ray->material_id;
-            ray->queue[0].group_id = end_group;
-            ray->queue[0].local0 = 0;
-            ray->queue[0].local1 = 0;
-            new_key = end_group;
-        }
+        done = visit_aabb<kAabbCap, kAabbThreads, false>(g, ray, a, s_pos, s_idx, tid, new_key);
     }
-    a.frame.next[index] = rt_index_pair{new_key, entry.slot};
+    if (done) a.frame.next[index] = rt_index_pair{new_key, entry.slot};
+    // Rare: lanes that need the large candidate list.  They are handed over wave by wave (first
+    // position + lane mask), so that the second kernel sees them grouped exactly as they are here.
+    const unsigned long long spilled = __ballot(!done);
+    if (spilled && lane_id() == (uint32_t)(__ffsll((long long)spilled) - 1))
+        spill_list[atomicAdd(&glob->spill_count, 1u)] = SpillEntry{spilled, index & ~63u, 0u};
+}
+
+// The rays the main kernel could not finish: one wave per entry of the hand-over list.
+__global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a, const SpillEntry *spill_list)
+{
+    __shared__ float s_pos[RT_MAX_HITS][kBigThreads];
+    __shared__ uint8_t s_idx[RT_MAX_HITS][kBigThreads];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t total = a.frame.glob->spill_count;
+    for (uint32_t at = blockIdx.x; at < total; at += gridDim.x) {
+        const SpillEntry e = spill_list[at];
+        if (!((e.lanes >> tid) & 1)) continue;
+        const uint32_t index = e.first + tid;
+        const rt_index_pair entry = a.frame.index[index];
+        const uint32_t key = entry.key;
+        RaySlot *ray = &a.frame.rays[entry.slot];
+        uint32_t new_key = key;
+        bool todo = true;
+        while (todo) {
+            if (key != __builtin_amdgcn_readfirstlane(key)) continue;
+            todo = false;
+            const uint32_t g = uniform_value(key);
+            visit_aabb<RT_MAX_HITS, kBigThreads, true>(g, ray, a, s_pos, s_idx, tid, new_key);
+        }
+        a.frame.next[index] = rt_index_pair{new_key, entry.slot};
+    }
 }
 
 // ---------------------------------------------------------------- queue compaction (ray-tracer.cl:235-302)
 
-// count_groups (ray-tracer.cl:235-253): count.s0[g] = number of sorted entries whose group id is <= g,
-// here found by one binary search per group instead of one boundary test per ray.
+// count_groups (ray-tracer.cl:235-253) and the per-group part of update_groups (:261-275), one thread
+// per group: E[g] = number of sorted entries whose group id is <= g comes from a binary search instead
+// of a boundary test per ray with a serial fill; with E[g-1] the thread has the group's new entries,
+// adds the rays parked earlier and splits the sum into whole warps and a parked remainder.
 __global__ void k_count_groups(const DevGlobal *glob, rt_group_data *grp_data, const rt_index_pair *sorted)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= glob->g.group_count) return;
-    uint32_t lo = 0, hi = glob->g.ray_count;
-    while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if ((sorted[mid].key & kIdMask) <= g) lo = mid + 1;
-        else hi = mid;
-    }
-    grp_data[g].count[0] = lo;
+    const uint32_t groups = glob->g.group_count, n = glob->g.ray_count;
+    if (g >= groups) return;
+    auto upper_bound = [&](uint32_t lo, uint32_t id) {
+        uint32_t hi = n;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if ((sorted[mid].key & kIdMask) <= id) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    const uint32_t start = g ? upper_bound(0, g - 1) : 0;
+    const uint32_t end = upper_bound(start, g);
+    const uint32_t main_count = end - start;
+    rt_group_data grp = grp_data[g];
+    grp.base[0] = start;
+    grp.base[1] = grp.offset[1] - main_count;
+    const uint32_t total = main_count + grp.count[1];
+    const uint32_t tail = g != groups - 1 ? total % glob->warp_width : total;  // the last group is the dead-ray bin
+    grp.count[0] = total - tail;
+    grp.count[1] = tail;
+    grp_data[g] = grp;
 }
 
 constexpr int kScanThreads = 1024;
+constexpr uint32_t kScanBatch = 8;
 
-// update_groups (ray-tracer.cl:255-291) as one work-group: each thread owns a contiguous run of
-// groups, the runs are chained by a block-wide exclusive scan of (aligned, parked) counts.
+// The prefix sums of update_groups (ray-tracer.cl:276-290) as one work-group: each thread owns a
+// contiguous run of groups, the runs are chained by a block-wide exclusive scan of (whole-warp, parked)
+// counts.  Loads are issued in batches so a thread pays one memory latency per batch, not per group.
 __global__ __launch_bounds__(kScanThreads) void k_update_groups(DevGlobal *glob, rt_group_data *grp_data)
 {
     __shared__ uint2 s_wave[kScanThreads / 64];
     __shared__ uint2 s_total;
-    const uint32_t n = glob->g.group_count, warp = glob->warp_width;
+    const uint32_t n = glob->g.group_count;
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + kScanThreads - 1) / kScanThreads;
-    const uint32_t first = tid * per, last = first + per < n ? first + per : n;
+    const uint32_t first = tid * per < n ? tid * per : n, last = first + per < n ? first + per : n;
 
-    // pass 1: this thread's totals
     uint2 mine = make_uint2(0, 0);
-    for (uint32_t pos = first; pos < last; pos++) {
-        const uint32_t start = pos ? grp_data[pos - 1].count[0] : 0;
-        uint32_t tot = grp_data[pos].count[0] - start + grp_data[pos].count[1];
-        uint32_t tail = tot;
-        if (pos != n - 1) tail %= warp;
-        mine.x += tot - tail;
-        mine.y += tail;
+    for (uint32_t at = first; at < last; at += kScanBatch) {
+        uint2 c[kScanBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBatch; k++)
+            c[k] = at + k < last ? *reinterpret_cast<const uint2 *>(grp_data[at + k].count) : make_uint2(0, 0);
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBatch; k++) {
+            mine.x += c[k].x;
+            mine.y += c[k].y;
+        }
     }
-    // block-wide exclusive scan of `mine`
     uint2 incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -630,35 +830,24 @@ __global__ __launch_bounds__(kScanThreads) void k_update_groups(DevGlobal *glob,
     uint2 offset = make_uint2(s_wave[tid >> 6].x + incl.x - mine.x, s_wave[tid >> 6].y + incl.y - mine.y);
     const uint32_t all_aligned = s_total.x;
 
-    // pass 2: write the group records
-    // end of the previous run, read before any thread writes (threads past the last group own nothing)
-    uint32_t carry = (first && first < n) ? grp_data[first - 1].count[0] : 0;
-    __syncthreads();
-    for (uint32_t pos = first; pos < last; pos++) {
-        rt_group_data grp;
-        const uint32_t end = grp_data[pos].count[0];
-        grp.base[0] = carry;
-        carry = end;
-        const uint32_t main_count = end - grp.base[0];
-        grp.base[1] = grp_data[pos].offset[1] - main_count;
-        const uint32_t tot = main_count + grp_data[pos].count[1];
-        uint32_t tail = tot;
-        if (pos != n - 1) tail %= warp;
-        grp.count[0] = tot - tail;
-        grp.count[1] = tail;
-        grp.offset[0] = offset.x;
-        grp.offset[1] = offset.y + all_aligned;
-        offset.x += grp.count[0];
-        offset.y += grp.count[1];
-        if (!pos) {
-            glob->g.pixel_offset += glob->g.pixel_count;
-            glob->g.pixel_count = grp.count[0];
+    for (uint32_t at = first; at < last; at += kScanBatch) {
+        uint2 c[kScanBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBatch; k++)
+            c[k] = at + k < last ? *reinterpret_cast<const uint2 *>(grp_data[at + k].count) : make_uint2(0, 0);
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBatch; k++) {
+            if (at + k < last) *reinterpret_cast<uint2 *>(grp_data[at + k].offset) = make_uint2(offset.x, offset.y + all_aligned);
+            offset.x += c[k].x;
+            offset.y += c[k].y;
         }
-        grp_data[pos] = grp;
     }
     if (tid == 0) {
+        glob->g.pixel_offset += glob->g.pixel_count;
+        glob->g.pixel_count = grp_data[0].count[0];
         glob->g.old_count = glob->g.ray_count;
         glob->g.ray_count = all_aligned;
+        glob->spill_count = 0;  // the next step's overflow list starts empty
     }
 }
 
@@ -723,7 +912,8 @@ void launch_load_rays(const LaunchCtx &c, const rt_ray *rays, uint32_t n_rays)
 void launch_process_traverse(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    k_process_aabb<<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a);
+    k_process_aabb<<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+    k_process_aabb_big<<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
 }
 
 void launch_process_misc(const LaunchCtx &c)

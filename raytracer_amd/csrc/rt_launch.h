@@ -11,6 +11,7 @@ struct LaunchCtx {
     Frame frame;
     rt_camera cam;
     rt_group_data *grp_data;
+    SpillEntry *spill_list;  // pool / 64 entries: waves with rays whose box visit overflowed the main kernel
     uint32_t pool, area_size, group_count;
 };
 
