@@ -13,9 +13,9 @@
 //     entry index maps lane -> bank (tid mod 32), conflict-free for 4-byte accesses;
 //   * the pending-node queue of a ray is merged straight into its slot in HBM from a register
 //     snapshot of the old entries -- no scratch memory;
-//   * box groups and everything else run as two kernels with different register/LDS budgets; both
-//     read the step's keys from `index` and write the new ones to `next`, so a ray advanced by one
-//     kernel is never picked up again by the other in the same step.
+//   * box groups and everything else run as two kernels with different register/LDS budgets, the
+//     box kernel first; both read the step's keys from `index` and write the new ones to `next`, so
+//     a ray advanced by one kernel is never picked up again by the other in the same step.
 #include "rt_device.h"
 
 namespace rtd {
@@ -415,72 +415,6 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     return end_group;
 }
 
-// ---------------------------------------------------------------- process, everything but box groups
-
-__global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t pool)
-{
-    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    const DevGlobal *glob = a.frame.glob;
-    if (index >= pool) return;
-    const rt_index_pair entry = a.frame.index[index];
-    if (index >= glob->g.ray_count) {  // parked entry: not processed, carried over
-        a.frame.next[index] = entry;
-        return;
-    }
-    const uint32_t key = entry.key;
-    RaySlot *ray = &a.frame.rays[entry.slot];
-    const uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
-    if (shader == RT_SH_AABB) return;
-    const uint32_t dead = a.group_count - 1;
-    const bool trace_only = (glob->mode & kModeTraceOnly) != 0;
-
-    uint32_t new_key = key;
-    bool todo = true;
-    while (todo) {
-        if (key != __builtin_amdgcn_readfirstlane(key)) continue;
-        todo = false;
-        const uint32_t g = uniform_value(key);  // every lane still here holds the same key
-        switch ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) {
-        case RT_SH_SPAWN: {
-            bool started;
-            new_key = init_ray(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
-            count_lanes(a.frame, kPrimarySpawned, started);
-            break;
-        }
-        case RT_SH_SKY:
-        case RT_SH_LIGHT:
-            if (trace_only) {
-                ray->queue[0].group_id = new_key = dead;
-                break;
-            }
-            new_key = sky_or_light_shader(a, ray, ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_LIGHT);
-            break;
-        case RT_SH_MATERIAL: {
-            if (trace_only) {
-                ray->queue[0].group_id = new_key = dead;
-                break;
-            }
-            const f32x4 color = *const_ptr<f32x4>(a.scene.grp + (g & kIdMask));
-            new_key = mat_shader(ray, make_float4(color.x, color.y, color.z, color.w));
-            count_lanes(a.frame, kShadowSpawned, true);
-            break;
-        }
-        case RT_SH_MESH:
-            new_key = visit_mesh(g, ray, a);
-            break;
-        default: {  // unknown shader type: the reference falls through to the pop (ray-tracer.cl:152-165)
-            const uint32_t queue_len = ray->queue_len;
-            const float head_pos = ray->queue[0].pos;
-            OldQueue old;
-            load_pending(old, ray, queue_len);
-            new_key = store_shifted(ray, old, queue_len - 1, head_pos, ray->material_id);
-            break;
-        }
-        }
-    }
-    a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
-}
-
 // ---------------------------------------------------------------- process, box groups
 // aabb_shader (shader.cl:76-101) + insert_hits (ray-tracer.cl:90-117, 205-231)
 //
@@ -718,15 +652,16 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, Sp
         spill_list[atomicAdd(&glob->spill_count, 1u)] = SpillEntry{spilled, index & ~63u, 0u};
 }
 
-// The rays the main kernel could not finish: one wave per entry of the hand-over list.
-__global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a, const SpillEntry *spill_list)
+// The rays the main kernel could not finish: one wave per entry of the hand-over list.  Runs as the
+// first kBigBlocks workgroups of k_process_misc (first wave of each), i.e. beside the leaf and shading
+// work instead of as a launch of its own: a lone wave scanning a 256-box list takes about 50 us, which
+// nothing would hide at the end of a launch.
+__device__ __forceinline__ void process_aabb_big(const ProcessArgs &a, const SpillEntry *spill_list,
+                                                 float (*s_pos)[kBigThreads], uint8_t (*s_idx)[kBigThreads])
 {
-    __shared__ float s_pos[RT_MAX_HITS][kBigThreads];
-    __shared__ uint8_t s_idx[RT_MAX_HITS][kBigThreads];
-
     const uint32_t tid = threadIdx.x;
     const uint32_t total = a.frame.glob->spill_count;
-    for (uint32_t at = blockIdx.x; at < total; at += gridDim.x) {
+    for (uint32_t at = blockIdx.x; at < total; at += kBigBlocks) {
         const SpillEntry e = spill_list[at];
         if (!((e.lanes >> tid) & 1)) continue;
         const uint32_t index = e.first + tid;
@@ -743,6 +678,78 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
         }
         a.frame.next[index] = rt_index_pair{new_key, entry.slot};
     }
+}
+
+// ---------------------------------------------------------------- process, everything but box groups
+
+__global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t pool, const SpillEntry *spill_list)
+{
+    __shared__ float s_pos[RT_MAX_HITS][kBigThreads];
+    __shared__ uint8_t s_idx[RT_MAX_HITS][kBigThreads];
+    if (blockIdx.x < kBigBlocks) {  // these workgroups finish the box visits the main kernel handed over
+        if (threadIdx.x < kBigThreads) process_aabb_big(a, spill_list, s_pos, s_idx);
+        return;
+    }
+    const uint32_t index = (blockIdx.x - kBigBlocks) * blockDim.x + threadIdx.x;
+    const DevGlobal *glob = a.frame.glob;
+    if (index >= pool) return;
+    const rt_index_pair entry = a.frame.index[index];
+    if (index >= glob->g.ray_count) {  // parked entry: not processed, carried over
+        a.frame.next[index] = entry;
+        return;
+    }
+    const uint32_t key = entry.key;
+    RaySlot *ray = &a.frame.rays[entry.slot];
+    const uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
+    if (shader == RT_SH_AABB) return;
+    const uint32_t dead = a.group_count - 1;
+    const bool trace_only = (glob->mode & kModeTraceOnly) != 0;
+
+    uint32_t new_key = key;
+    bool todo = true;
+    while (todo) {
+        if (key != __builtin_amdgcn_readfirstlane(key)) continue;
+        todo = false;
+        const uint32_t g = uniform_value(key);  // every lane still here holds the same key
+        switch ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) {
+        case RT_SH_SPAWN: {
+            bool started;
+            new_key = init_ray(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
+            count_lanes(a.frame, kPrimarySpawned, started);
+            break;
+        }
+        case RT_SH_SKY:
+        case RT_SH_LIGHT:
+            if (trace_only) {
+                ray->queue[0].group_id = new_key = dead;
+                break;
+            }
+            new_key = sky_or_light_shader(a, ray, ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_LIGHT);
+            break;
+        case RT_SH_MATERIAL: {
+            if (trace_only) {
+                ray->queue[0].group_id = new_key = dead;
+                break;
+            }
+            const f32x4 color = *const_ptr<f32x4>(a.scene.grp + (g & kIdMask));
+            new_key = mat_shader(ray, make_float4(color.x, color.y, color.z, color.w));
+            count_lanes(a.frame, kShadowSpawned, true);
+            break;
+        }
+        case RT_SH_MESH:
+            new_key = visit_mesh(g, ray, a);
+            break;
+        default: {  // unknown shader type: the reference falls through to the pop (ray-tracer.cl:152-165)
+            const uint32_t queue_len = ray->queue_len;
+            const float head_pos = ray->queue[0].pos;
+            OldQueue old;
+            load_pending(old, ray, queue_len);
+            new_key = store_shifted(ray, old, queue_len - 1, head_pos, ray->material_id);
+            break;
+        }
+        }
+    }
+    a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 }
 
 // ---------------------------------------------------------------- queue compaction (ray-tracer.cl:235-302)
@@ -913,13 +920,12 @@ void launch_process_traverse(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
     k_process_aabb<<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
-    k_process_aabb_big<<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
 }
 
 void launch_process_misc(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    k_process_misc<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
+    k_process_misc<<<dim3(grid_for(c.pool, 256).x + kBigBlocks), 256, 0, c.stream>>>(a, c.pool, c.spill_list);
 }
 
 void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst)
