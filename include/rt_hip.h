@@ -209,10 +209,16 @@ int rt_trace_closest(rt_ctx *ctx, const rt_ray *rays, uint32_t n_rays, rt_hit_re
 
 /* -------------------------------------------------------------- profiling */
 
-enum { RT_STAGE_TRAVERSE = 0, RT_STAGE_SHADE = 1, RT_STAGE_SORT = 2, RT_STAGE_COMPACT = 3, RT_STAGE_COUNT = 4 };
+/* Stages of a step: box-group visits, shading + spawn, ray-key sort, queue compaction, leaf (triangle)
+ * visits.  The leaf kernel runs on a second stream beside the box and shading kernels. */
+enum { RT_STAGE_TRAVERSE = 0, RT_STAGE_SHADE = 1, RT_STAGE_SORT = 2, RT_STAGE_COMPACT = 3, RT_STAGE_LEAVES = 4, RT_STAGE_COUNT = 5 };
 
-/* When enabled, rt_step brackets every stage with HIP events on the context's stream. */
-int rt_set_profiling(rt_ctx *ctx, int enabled);
+/* RT_PROFILE_STAGES: rt_step brackets every stage with HIP events on the stream the stage is launched
+ * on; the schedule is unchanged, so the box, shading and leaf spans overlap.  RT_PROFILE_SERIAL: the
+ * same, with the leaf kernel on the main stream between the box and shading kernels, so each span is
+ * that kernel's duration alone.  Both cost throughput (event records between kernels). */
+enum { RT_PROFILE_OFF = 0, RT_PROFILE_STAGES = 1, RT_PROFILE_SERIAL = 2 };
+int rt_set_profiling(rt_ctx *ctx, int mode);
 /* Sum of stage durations in milliseconds and number of timed steps since profiling was enabled. */
 int rt_get_stage_times(rt_ctx *ctx, double ms[RT_STAGE_COUNT], uint64_t *steps);
 

@@ -13,7 +13,7 @@ from . import layout as L
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "csrc", "librt_hip.so")
 
-STAGE_NAMES = ("traverse", "shade", "sort", "compact")
+STAGE_NAMES = ("traverse", "shade", "sort", "compact", "leaves")
 
 EXPORTS = (
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_init_frame", "rt_step", "rt_set_warp_width", "rt_sync",
@@ -205,8 +205,9 @@ class RayTracer:
                                                grp.ctypes.data, glob.ctypes.data, warp_width))
         return out, grp, glob
 
-    def set_profiling(self, enabled):
-        self._check(self.lib.rt_set_profiling(self.h, int(bool(enabled))))
+    def set_profiling(self, mode):
+        """0 off, 1 stage timers on the concurrent schedule, 2 stage timers with the kernels serialised."""
+        self._check(self.lib.rt_set_profiling(self.h, int(mode)))
 
     def stage_times(self):
         """({stage: total ms}, timed steps) since profiling was enabled."""

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,7 +19,8 @@ using namespace rtd;
 
 struct rt_ctx {
     rt_config cfg{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, side = nullptr;  // side: leaf kernel, concurrent with the box and shading kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t pool = 0, area_size = 0, group_count = 0;
     bool scene_ready = false, frame_ready = false;
 
@@ -43,9 +45,14 @@ struct rt_ctx {
 
     uint64_t steps = 0;
     bool profiling = false;
-    std::vector<hipEvent_t> pending;  // 5 events per timed step
+    bool serial = false;  // stage timing with the process kernels one after another on one stream
+    struct Span {
+        int stage;
+        hipEvent_t from, to;
+    };
+    std::vector<Span> pending;  // one per stage and timed step
     std::vector<hipEvent_t> spare;
-    double stage_ms[RT_STAGE_COUNT] = {0, 0, 0, 0};
+    double stage_ms[RT_STAGE_COUNT] = {0, 0, 0, 0, 0};
     uint64_t timed_steps = 0;
 
     std::string last_error;
@@ -149,30 +156,45 @@ int resolve_timers(rt_ctx *c)
 {
     if (c->pending.empty()) return RT_OK;
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i + 4 < c->pending.size(); i += 5) {
-        for (int s = 0; s < RT_STAGE_COUNT; s++) {
-            float ms = 0;
-            RT_HIP(c, hipEventElapsedTime(&ms, c->pending[i + s], c->pending[i + s + 1]));
-            c->stage_ms[s] += ms;
-        }
-        c->timed_steps++;
+    if (c->side) RT_HIP(c, hipStreamSynchronize(c->side));
+    for (const rt_ctx::Span &span : c->pending) {
+        float ms = 0;
+        RT_HIP(c, hipEventElapsedTime(&ms, span.from, span.to));
+        c->stage_ms[span.stage] += ms;
+        if (span.stage == RT_STAGE_COMPACT) c->timed_steps++;
+        c->spare.push_back(span.from);
+        c->spare.push_back(span.to);
     }
-    c->spare.insert(c->spare.end(), c->pending.begin(), c->pending.end());
     c->pending.clear();
     return RT_OK;
 }
 
-int mark(rt_ctx *c)
+int new_event(rt_ctx *c, hipEvent_t &ev, hipStream_t stream)
 {
-    hipEvent_t ev;
     if (!c->spare.empty()) {
         ev = c->spare.back();
         c->spare.pop_back();
     } else {
         RT_HIP(c, hipEventCreate(&ev));
     }
-    c->pending.push_back(ev);
-    RT_HIP(c, hipEventRecord(ev, c->stream));
+    RT_HIP(c, hipEventRecord(ev, stream));
+    return RT_OK;
+}
+
+// Brackets what `launch` enqueues on `stream` with two events when stage timing is on.
+template <typename Launch>
+int timed(rt_ctx *c, int stage, hipStream_t stream, Launch launch)
+{
+    if (!c->profiling) {
+        launch();
+        return RT_OK;
+    }
+    rt_ctx::Span span{stage, nullptr, nullptr};
+    int rc = new_event(c, span.from, stream);
+    if (rc) return rc;
+    launch();
+    if ((rc = new_event(c, span.to, stream))) return rc;
+    c->pending.push_back(span);
     return RT_OK;
 }
 
@@ -182,15 +204,26 @@ int one_step(rt_ctx *c, bool run_process)
 {
     const LaunchCtx l = launch_ctx(c);
     int rc;
-    if (c->profiling && (rc = mark(c))) return rc;
-    if (run_process) launch_process_traverse(l);
-    if (c->profiling && (rc = mark(c))) return rc;
-    if (run_process) launch_process_misc(l);
-    if (c->profiling && (rc = mark(c))) return rc;
-    launch_sort(c->stream, c->ws, run_process ? c->next : c->index, c->sorted, c->pool, &c->glob->g.ray_count, c->group_count);
-    if (c->profiling && (rc = mark(c))) return rc;
-    launch_compact(l, c->sorted, c->index);
-    if (c->profiling && (rc = mark(c))) return rc;
+    if (run_process) {
+        // Box, leaf and shader groups touch disjoint rays within a step.  The leaf kernel runs on the
+        // side stream beside the other two; the sort waits for both streams.
+        const bool fork = c->side && !c->serial;
+        hipStream_t leaf_stream = fork ? c->side : c->stream;
+        if (fork) {
+            RT_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+            RT_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        }
+        if ((rc = timed(c, RT_STAGE_TRAVERSE, c->stream, [&] { launch_process_boxes(l); }))) return rc;
+        if ((rc = timed(c, RT_STAGE_LEAVES, leaf_stream, [&] { launch_process_leaves(l, leaf_stream); }))) return rc;
+        if (fork) RT_HIP(c, hipEventRecord(c->ev_join, c->side));
+        if ((rc = timed(c, RT_STAGE_SHADE, c->stream, [&] { launch_process_shade(l); }))) return rc;
+        if (fork) RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
+    rc = timed(c, RT_STAGE_SORT, c->stream, [&] {
+        launch_sort(c->stream, c->ws, run_process ? c->next : c->index, c->sorted, c->pool, &c->glob->g.ray_count, c->group_count);
+    });
+    if (rc) return rc;
+    if ((rc = timed(c, RT_STAGE_COMPACT, c->stream, [&] { launch_compact(l, c->sorted, c->index); }))) return rc;
     if (c->profiling && c->pending.size() >= 5 * 2048 && (rc = resolve_timers(c))) return rc;
     return check_launch(c, "make_step");
 }
@@ -239,6 +272,11 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
 
     RT_HIP(c, hipSetDevice(cfg->device));
     RT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (!getenv("RT_NO_OVERLAP")) {
+        RT_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        RT_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        RT_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
     RT_HIP(c, dev_alloc(c->glob, 1));
     RT_HIP(c, dev_alloc(c->counters, size_t(kCounterShards) * kCounterKinds));
     RT_HIP(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * kCounterShards * kCounterKinds, c->stream));
@@ -267,7 +305,10 @@ int rt_destroy(rt_ctx *c)
     if (!c) return RT_ERR_INVALID_VALUE;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (hipEvent_t ev : c->pending) (void)hipEventDestroy(ev);
+    for (const rt_ctx::Span &span : c->pending) {
+        (void)hipEventDestroy(span.from);
+        (void)hipEventDestroy(span.to);
+    }
     for (hipEvent_t ev : c->spare) (void)hipEventDestroy(ev);
     free_scene(c);
     dev_free(c->glob);
@@ -283,6 +324,10 @@ int rt_destroy(rt_ctx *c)
     dev_free(c->hits);
     dev_free(c->rgba);
     dev_free(c->spill_list);
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
@@ -687,6 +732,7 @@ int rt_set_profiling(rt_ctx *c, int enabled)
     const int rc = resolve_timers(c);
     if (rc) return rc;
     c->profiling = enabled != 0;
+    c->serial = enabled == RT_PROFILE_SERIAL;
     if (enabled) {
         for (double &ms : c->stage_ms) ms = 0;
         c->timed_steps = 0;

@@ -166,6 +166,14 @@ __device__ __forceinline__ uint32_t uniform_value(uint32_t v)
     return s;
 }
 
+// Waits for every scalar load (and LDS access) issued so far.  Scalar loads return out of order, so a
+// wave can only wait for all of them; in a software-pipelined scan this goes BEFORE the request for the
+// next batch, otherwise the first use of the current batch waits for the batch just requested as well.
+__device__ __forceinline__ void scalar_loads_landed()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt and expcnt untouched
+}
+
 // Largest v (0..127) among the ACTIVE lanes of the wave, by bisection with ballots; unlike a shuffle
 // reduction it never looks at the registers of lanes that are switched off.
 __device__ __forceinline__ uint32_t wave_max_upto127(uint32_t v)

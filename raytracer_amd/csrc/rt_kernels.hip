@@ -13,12 +13,28 @@
 //     entry index maps lane -> bank (tid mod 32), conflict-free for 4-byte accesses;
 //   * the pending-node queue of a ray is merged straight into its slot in HBM from a register
 //     snapshot of the old entries -- no scratch memory;
-//   * box groups and everything else run as two kernels with different register/LDS budgets, the
-//     box kernel first; both read the step's keys from `index` and write the new ones to `next`, so
+//   * box groups, leaf groups and shader groups run as three kernels with different register/LDS
+//     budgets, the box kernel first; both read the step's keys from `index` and write the new ones to `next`, so
 //     a ray advanced by one kernel is never picked up again by the other in the same step.
 #include "rt_device.h"
 
 namespace rtd {
+
+// Phase stamps of diagnostic builds: -DRT_STAMPS=1 times the box-group kernel, =2 the leaf/shading kernel.
+#if defined(RT_STAMPS) && RT_STAMPS == 1
+#define AABB_STAMP(v) RT_STAMP(v)
+#define AABB_STAMP_ADD(f, s, a, b) RT_STAMP_ADD(f, s, a, b)
+#else
+#define AABB_STAMP(v)
+#define AABB_STAMP_ADD(f, s, a, b)
+#endif
+#if defined(RT_STAMPS) && RT_STAMPS == 2
+#define MISC_STAMP(v) RT_STAMP(v)
+#define MISC_STAMP_ADD(f, s, a, b) RT_STAMP_ADD(f, s, a, b)
+#else
+#define MISC_STAMP(v)
+#define MISC_STAMP_ADD(f, s, a, b)
+#endif
 
 struct ProcessArgs {
     Scene scene;
@@ -299,6 +315,7 @@ __device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color)
 
 __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const ProcessArgs &a)
 {
+    MISC_STAMP(t_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // vtx_offs, tri_offs, tri_count, material_id
     // The slot's first 128-byte line (meta, ray, queue[0..4]) is requested at once and the rest of the
     // queue if it is that long, so that the triangle scan covers the latency.
@@ -322,6 +339,10 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     // starts on an even index, is filled up to an even count with null triangles and is followed by
     // readable entries, so the next pair is always requested before the current pair is tested.
     ConstPtr<f32x8> rec = const_ptr<f32x8>(a.scene.tri_rec + grp.y);
+#if defined(RT_STAMPS) && RT_STAMPS == 2
+    asm volatile("" ::"v"(lr.start.x), "v"(lr.dir.x), "v"(lr.tmin));
+#endif
+    MISC_STAMP(t_loaded);
     float best = lr.tmax, hit_u = 0, hit_v = 0;
     uint32_t hit_index = 0xFFFFFFFFu;
     const uint32_t count = grp.z;
@@ -347,9 +368,11 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
         f32x8 a0 = rec[0], a1 = rec[1], a2 = rec[2];
         for (uint32_t i = 0;; i += 4) {
             const uint32_t at = 3 * (i / 2);
+            scalar_loads_landed();  // a0..a2 are in; only then ask for the next pair
             const f32x8 b0 = rec[at + 3], b1 = rec[at + 4], b2 = rec[at + 5];
             test_two(a0, a1, a2, i);
             if (i + 2 >= count) break;
+            scalar_loads_landed();
             a0 = rec[at + 6];
             a1 = rec[at + 7];
             a2 = rec[at + 8];
@@ -358,6 +381,9 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
         }
     }
 
+    MISC_STAMP(t_scanned);
+    MISC_STAMP_ADD(a.frame, 0, t_start, t_loaded);
+    MISC_STAMP_ADD(a.frame, 1, t_loaded, t_scanned);
     // Miss: pop the head (ray-tracer.cl:154-165).  Hit: insert_stop (ray-tracer.cl:173-203).  What a
     // hit still needs from memory (shading normal, sample id, or the shadow weight) is loaded before
     // the first store of this visit.
@@ -446,7 +472,7 @@ template <int CAP, int THREADS, bool BIG>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
                                            uint8_t (*s_idx)[THREADS], uint32_t tid, uint32_t &new_key)
 {
-    RT_STAMP(t_start);
+    AABB_STAMP(t_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
     const uint32_t count = grp.y;
     // Everything this visit needs from the ray slot is requested now, so that the box scan covers the
@@ -474,7 +500,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     // per half iteration without tail handling, while the loads for the next four are in flight.
     ConstPtr<f32x16> pair = const_ptr<f32x16>(a.scene.aabb + grp.x);  // per box: min.xyz, group id, max.xyz, local id
     asm volatile("" ::"v"(inv_dir.x), "v"(inv_dir.y), "v"(inv_dir.z), "v"(lr.start.x));
-    RT_STAMP(t_loaded);
+    AABB_STAMP(t_loaded);
     uint32_t n = 0;
     bool spill = false;
     auto test_pair = [&](const f32x16 p, uint32_t i) {
@@ -503,10 +529,12 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     if (count) {
         f32x16 a0 = pair[0], a1 = pair[1];
         for (uint32_t i = 0;; i += 8) {
+            scalar_loads_landed();  // a0, a1 are in; only then ask for the next four
             const f32x16 b0 = pair[i / 2 + 2], b1 = pair[i / 2 + 3];
             test_pair(a0, i);
             test_pair(a1, i + 2);
             if (i + 4 >= count) break;
+            scalar_loads_landed();
             a0 = pair[i / 2 + 4];
             a1 = pair[i / 2 + 5];
             test_pair(b0, i + 4);
@@ -514,9 +542,9 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
             if (i + 8 >= count) break;
         }
     }
-    RT_STAMP(t_scanned);
-    RT_STAMP_ADD(a.frame, 0, t_start, t_loaded);
-    RT_STAMP_ADD(a.frame, 1, t_loaded, t_scanned);
+    AABB_STAMP(t_scanned);
+    AABB_STAMP_ADD(a.frame, 0, t_start, t_loaded);
+    AABB_STAMP_ADD(a.frame, 1, t_loaded, t_scanned);
     if (spill) {
         if (!BIG) return false;
         n = 0;  // more than 64 candidates: the reference gives up on the whole node
@@ -543,8 +571,8 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
                 if (i & offs) exchange(i - offs, i);
     }
 
-    RT_STAMP(t_sorted);
-    RT_STAMP_ADD(a.frame, 2, t_scanned, t_sorted);
+    AABB_STAMP(t_sorted);
+    AABB_STAMP_ADD(a.frame, 2, t_scanned, t_sorted);
     // insert_hits (ray-tracer.cl:205-231): merge the sorted candidates with the pending entries, old
     // entry first on equal position, at most 8 entries, the 8th turned into a root restart.  Both
     // lists are sorted, so every entry's place in the merged queue is a count: a pending entry i goes
@@ -617,8 +645,8 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         ray->queue[0].local1 = 0;
         new_key = end_group;
     }
-    RT_STAMP(t_merged);
-    RT_STAMP_ADD(a.frame, 3, t_sorted, t_merged);
+    AABB_STAMP(t_merged);
+    AABB_STAMP_ADD(a.frame, 3, t_sorted, t_merged);
     return true;
 }
 
@@ -653,7 +681,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, Sp
 }
 
 // The rays the main kernel could not finish: one wave per entry of the hand-over list.  Runs as the
-// first kBigBlocks workgroups of k_process_misc (first wave of each), i.e. beside the leaf and shading
+// first kBigBlocks workgroups of k_process_shade (first wave of each), i.e. beside the shading
 // work instead of as a launch of its own: a lone wave scanning a 256-box list takes about 50 us, which
 // nothing would hide at the end of a launch.
 __device__ __forceinline__ void process_aabb_big(const ProcessArgs &a, const SpillEntry *spill_list,
@@ -682,11 +710,37 @@ __device__ __forceinline__ void process_aabb_big(const ProcessArgs &a, const Spi
 
 // ---------------------------------------------------------------- process, everything but box groups
 
-__global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t pool, const SpillEntry *spill_list)
+// Leaf groups: triangle scan + hit commit.
+__global__ __launch_bounds__(256) void k_process_mesh(ProcessArgs a)
+{
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= a.frame.glob->g.ray_count) return;
+    const rt_index_pair entry = a.frame.index[index];
+    const uint32_t key = entry.key;
+    if (((key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) != RT_SH_MESH) return;
+    RaySlot *ray = &a.frame.rays[entry.slot];
+
+    uint32_t new_key = key;
+    bool todo = true;
+    while (todo) {
+        if (key != __builtin_amdgcn_readfirstlane(key)) continue;
+        todo = false;
+        const uint32_t g = uniform_value(key);  // every lane still here holds the same key
+        MISC_STAMP(t_mesh0);
+        new_key = visit_mesh(g, ray, a);
+        MISC_STAMP(t_mesh1);
+        MISC_STAMP_ADD(a.frame, 2, t_mesh0, t_mesh1);
+    }
+    a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
+}
+
+// Shader groups (spawn, sky, light, material), parked entries, and -- in the first kBigBlocks
+// workgroups -- the box visits the main box kernel handed over.
+__global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t pool, const SpillEntry *spill_list)
 {
     __shared__ float s_pos[RT_MAX_HITS][kBigThreads];
     __shared__ uint8_t s_idx[RT_MAX_HITS][kBigThreads];
-    if (blockIdx.x < kBigBlocks) {  // these workgroups finish the box visits the main kernel handed over
+    if (blockIdx.x < kBigBlocks) {
         if (threadIdx.x < kBigThreads) process_aabb_big(a, spill_list, s_pos, s_idx);
         return;
     }
@@ -699,9 +753,9 @@ __global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t po
         return;
     }
     const uint32_t key = entry.key;
-    RaySlot *ray = &a.frame.rays[entry.slot];
     const uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
-    if (shader == RT_SH_AABB) return;
+    if (shader == RT_SH_AABB || shader == RT_SH_MESH) return;
+    RaySlot *ray = &a.frame.rays[entry.slot];
     const uint32_t dead = a.group_count - 1;
     const bool trace_only = (glob->mode & kModeTraceOnly) != 0;
 
@@ -711,6 +765,7 @@ __global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t po
         if (key != __builtin_amdgcn_readfirstlane(key)) continue;
         todo = false;
         const uint32_t g = uniform_value(key);  // every lane still here holds the same key
+        MISC_STAMP(t_case0);
         switch ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) {
         case RT_SH_SPAWN: {
             bool started;
@@ -736,9 +791,6 @@ __global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t po
             count_lanes(a.frame, kShadowSpawned, true);
             break;
         }
-        case RT_SH_MESH:
-            new_key = visit_mesh(g, ray, a);
-            break;
         default: {  // unknown shader type: the reference falls through to the pop (ray-tracer.cl:152-165)
             const uint32_t queue_len = ray->queue_len;
             const float head_pos = ray->queue[0].pos;
@@ -748,6 +800,8 @@ __global__ __launch_bounds__(256) void k_process_misc(ProcessArgs a, uint32_t po
             break;
         }
         }
+        MISC_STAMP(t_case1);
+        MISC_STAMP_ADD(a.frame, 3, t_case0, t_case1);
     }
     a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 }
@@ -916,16 +970,22 @@ void launch_load_rays(const LaunchCtx &c, const rt_ray *rays, uint32_t n_rays)
     k_load_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool, rays, n_rays);
 }
 
-void launch_process_traverse(const LaunchCtx &c)
+void launch_process_boxes(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
     k_process_aabb<<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
 }
 
-void launch_process_misc(const LaunchCtx &c)
+void launch_process_leaves(const LaunchCtx &c, hipStream_t stream)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    k_process_misc<<<dim3(grid_for(c.pool, 256).x + kBigBlocks), 256, 0, c.stream>>>(a, c.pool, c.spill_list);
+    k_process_mesh<<<grid_for(c.pool, 256), 256, 0, stream>>>(a);
+}
+
+void launch_process_shade(const LaunchCtx &c)
+{
+    ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
+    k_process_shade<<<dim3(grid_for(c.pool, 256).x + kBigBlocks), 256, 0, c.stream>>>(a, c.pool, c.spill_list);
 }
 
 void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst)

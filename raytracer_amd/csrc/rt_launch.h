@@ -17,8 +17,11 @@ struct LaunchCtx {
 
 void launch_init_frame(const LaunchCtx &c);
 void launch_load_rays(const LaunchCtx &c, const rt_ray *rays_dev, uint32_t n_rays);
-void launch_process_traverse(const LaunchCtx &c);
-void launch_process_misc(const LaunchCtx &c);
+// The three process kernels touch disjoint rays; only launch_process_shade depends on another one
+// (it finishes the box visits launch_process_boxes handed over), so leaves may run on another stream.
+void launch_process_boxes(const LaunchCtx &c);
+void launch_process_leaves(const LaunchCtx &c, hipStream_t stream);
+void launch_process_shade(const LaunchCtx &c);
 void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst);
 void launch_compact_raw(hipStream_t stream, DevGlobal *glob, rt_group_data *grp_data, const rt_index_pair *sorted,
                         rt_index_pair *dst, uint32_t count, uint32_t group_count);

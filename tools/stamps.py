@@ -1,7 +1,8 @@
 """Developer tool: per-phase cycle shares of the box-group kernel from a -DRT_STAMPS build."""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["RT_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "csrc", "librt_hip_stamps.so")
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "1"
+os.environ["RT_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "csrc", f"librt_hip_stamps{WHICH}.so")
 from raytracer_amd import api, scene as S
 dragon = os.path.join(tempfile.gettempdir(), "rt_dragon_standin_tool.ply")
 if not os.path.exists(dragon):
@@ -12,7 +13,7 @@ rt.init_frame(); rt.make_step(96); rt.sync()
 rt.debug_stamps(reset=True)
 rt.make_step(32); rt.sync()
 st = rt.debug_stamps()
-names = ["load+transform", "box scan", "hit network", "merge+store", "big:load", "big:scan", "big:network", "big:merge"]
-tot = sum(st[:4]) or 1
+names = {"1": ["load+transform", "box scan", "hit network", "merge+store"],
+         "2": ["leaf: load", "leaf: scan", "leaf: whole visit", "all cases (incl. leaf)"]}[WHICH]
 for n, v in zip(names, st):
-    print(f"{n:16s} {v/32/1e6:10.2f} Mcycles/step  {100*v/tot:6.1f}% of main kernel")
+    print(f"{n:24s} {v/32/1e6:10.2f} Mcycles/step")
