@@ -42,9 +42,13 @@ clean:
 	rm -f $(CSRC)/librt_hip.so $(HOST)/librt_host.so $(HOST)/rt_main
 	$(MAKE) -C oracle clean
 
-.PHONY: all device host oracle clean stamps
+.PHONY: all device host oracle clean stamps variant
 
 # Diagnostic build with per-phase cycle stamps in the kernels (never loaded by default; RT_HIP_LIB selects it).
 stamps: $(CSRC)/librt_hip_stamps1.so $(CSRC)/librt_hip_stamps2.so
 $(CSRC)/librt_hip_stamps%.so: $(HIP_SOURCES) $(HIP_HEADERS)
 	$(HIPCC) $(HIPFLAGS) -DRT_STAMPS=$* $(HIP_SOURCES) -o $@
+
+# Experimental build with extra defines: make variant NAME=x DEFS="-DRT_AABB_THREADS=64" -> librt_hip_var_x.so
+variant:
+	$(HIPCC) $(HIPFLAGS) $(DEFS) $(HIP_SOURCES) -o $(CSRC)/librt_hip_var_$(NAME).so

@@ -32,6 +32,7 @@ struct rt_ctx {
     rt_hit_record *hits = nullptr;
     rt_group_data *grp_data = nullptr;
     SpillEntry *spill_list = nullptr;
+    CompactWorkspace compact = {nullptr, nullptr, nullptr};
     uchar4 *rgba = nullptr;
     SortWorkspace ws{};
 
@@ -101,6 +102,7 @@ LaunchCtx launch_ctx(const rt_ctx *c)
     l.cam = c->cam;
     l.grp_data = c->grp_data;
     l.spill_list = c->spill_list;
+    l.compact = c->compact;
     l.pool = c->pool;
     l.area_size = c->area_size;
     l.group_count = c->group_count;
@@ -114,6 +116,22 @@ int check_launch(rt_ctx *ctx, const char *what)
     return RT_OK;
 }
 
+void free_compact(CompactWorkspace &ws)
+{
+    dev_free(ws.move);
+    dev_free(ws.block_sums);
+    dev_free(ws.ticket);
+}
+
+hipError_t alloc_compact(CompactWorkspace &ws, uint32_t group_count)
+{
+    hipError_t err = dev_alloc(ws.move, group_count);
+    if (err == hipSuccess) err = dev_alloc(ws.block_sums, compact_group_blocks(group_count) + 1);
+    if (err == hipSuccess) err = dev_alloc(ws.ticket, 1);
+    if (err == hipSuccess) err = hipMemset(ws.ticket, 0, sizeof(uint32_t));
+    return err;
+}
+
 void free_scene(rt_ctx *c)
 {
     dev_free(c->grp);
@@ -123,6 +141,7 @@ void free_scene(rt_ctx *c)
     dev_free(c->tri);
     dev_free(c->tri_rec);
     dev_free(c->grp_data);
+    free_compact(c->compact);
     c->scene_ready = c->frame_ready = false;
 }
 
@@ -440,6 +459,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     RT_HIP(c, dev_alloc(c->tri, dev_tri.size()));
     RT_HIP(c, dev_alloc(c->tri_rec, dev_rec.size()));
     RT_HIP(c, dev_alloc(c->grp_data, G));
+    RT_HIP(c, alloc_compact(c->compact, G));
     RT_HIP(c, hipMemset(c->grp, 0, sizeof(rt_group) * size_t(G)));
     RT_HIP(c, hipMemset(c->grp_data, 0, sizeof(rt_group_data) * size_t(G)));
     RT_HIP(c, hipMemcpy(c->grp, dev_grp.data(), sizeof(rt_group) * n_groups, hipMemcpyHostToDevice));
@@ -618,10 +638,12 @@ int rt_compact_groups(rt_ctx *c, const rt_index_pair *sorted, rt_index_pair *out
     DevGlobal *d_glob = nullptr;
     rt_group_data *d_grp = nullptr;
     rt_index_pair *d_in = nullptr, *d_out = nullptr;
+    CompactWorkspace ws = {nullptr, nullptr, nullptr};
     int rc = RT_OK;
     auto step = [&](hipError_t err, const char *what) {
         if (err != hipSuccess && !rc) rc = fail(c, RT_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
     };
+    step(alloc_compact(ws, G), "alloc");
     step(dev_alloc(d_glob, 1), "alloc");
     step(dev_alloc(d_grp, G), "alloc");
     step(dev_alloc(d_in, count), "alloc");
@@ -633,7 +655,7 @@ int rt_compact_groups(rt_ctx *c, const rt_index_pair *sorted, rt_index_pair *out
         step(hipMemsetAsync(d_out, 0, sizeof(rt_index_pair) * size_t(count), c->stream), "clear");
     }
     if (!rc) {
-        launch_compact_raw(c->stream, d_glob, d_grp, d_in, d_out, count, G);
+        launch_compact_raw(c->stream, d_glob, d_grp, ws, d_in, d_out, count, G);
         rc = check_launch(c, "compact");
     }
     if (!rc) {
@@ -643,6 +665,7 @@ int rt_compact_groups(rt_ctx *c, const rt_index_pair *sorted, rt_index_pair *out
     }
     step(hipStreamSynchronize(c->stream), "compact");
     if (!rc) *global = host.g;
+    free_compact(ws);
     dev_free(d_glob);
     dev_free(d_grp);
     dev_free(d_in);

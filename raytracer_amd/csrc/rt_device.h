@@ -62,6 +62,21 @@ struct SpillEntry {
     uint32_t first, pad;
 };
 
+// Queue compaction: what moving an entry of group g needs, and the per-block prefix sums.
+constexpr int kGroupThreads = 256;  // groups per workgroup of the counting kernel
+struct GroupMove {
+    uint32_t base0, base1;  // first sorted position of the group's new entries / of its parked entries, as in rt_group_data
+    uint32_t count1;        // rays parked after this step
+    uint32_t off0, off1;    // whole-warp and parked rays of the earlier groups of the same block
+    uint32_t pad[3];
+};
+static_assert(sizeof(GroupMove) == 32, "GroupMove is read as one 32-byte record");
+struct CompactWorkspace {
+    GroupMove *move;     // [group_count]
+    uint2 *block_sums;   // [blocks + 1]: totals per block of kGroupThreads groups, then their exclusive prefix sums; last: group 0's whole warps
+    uint32_t *ticket;    // blocks finished; zero between launches
+};
+
 struct Scene {
     const rt_group *grp;
     const rt_matrix *mat;

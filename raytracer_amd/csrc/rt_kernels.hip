@@ -449,7 +449,14 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
 // occupancy is then 5 waves per SIMD instead of 2); a lane that accepts a 25th box leaves its ray
 // untouched and queues it for the second kernel, which has room for the reference's 64 candidates.
 
-constexpr int kAabbThreads = 256;  // main kernel
+#ifndef RT_AABB_THREADS
+#define RT_AABB_THREADS 256
+#endif
+#ifndef RT_MESH_THREADS
+#define RT_MESH_THREADS 256
+#endif
+constexpr int kAabbThreads = RT_AABB_THREADS;  // main kernel
+constexpr int kMeshThreads = RT_MESH_THREADS;
 constexpr int kAabbCap = 24;
 constexpr int kBigThreads = 64;    // overflow kernel: one wave per block
 constexpr int kBigBlocks = 256;
@@ -711,7 +718,7 @@ __device__ __forceinline__ void process_aabb_big(const ProcessArgs &a, const Spi
 // ---------------------------------------------------------------- process, everything but box groups
 
 // Leaf groups: triangle scan + hit commit.
-__global__ __launch_bounds__(256) void k_process_mesh(ProcessArgs a)
+__global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
 {
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= a.frame.glob->g.ray_count) return;
@@ -807,65 +814,57 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
 }
 
 // ---------------------------------------------------------------- queue compaction (ray-tracer.cl:235-302)
+//
+// Two launches.  k_count_groups: one thread per group finds the group's run in the sorted list, splits
+// it (plus the rays parked earlier) into whole warps and a parked remainder, and takes part in a
+// block-wide prefix sum; the last block to finish turns the block totals into block offsets and
+// updates the frame counters.  k_set_ray_index: one thread per entry moves it to its place, adding
+// its group's block offset on the fly; its first blocks write the finished offsets into the group
+// table.  No workgroup waits for another one.
 
-// count_groups (ray-tracer.cl:235-253) and the per-group part of update_groups (:261-275), one thread
-// per group: E[g] = number of sorted entries whose group id is <= g comes from a binary search instead
-// of a boundary test per ray with a serial fill; with E[g-1] the thread has the group's new entries,
-// adds the rays parked earlier and splits the sum into whole warps and a parked remainder.
-__global__ void k_count_groups(const DevGlobal *glob, rt_group_data *grp_data, const rt_index_pair *sorted)
+// count_groups (ray-tracer.cl:235-253) + update_groups (:255-290)
+__global__ __launch_bounds__(kGroupThreads) void k_count_groups(DevGlobal *glob, rt_group_data *grp_data,
+                                                                 const rt_index_pair *sorted, CompactWorkspace ws)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t groups = glob->g.group_count, n = glob->g.ray_count;
-    if (g >= groups) return;
-    auto upper_bound = [&](uint32_t lo, uint32_t id) {
-        uint32_t hi = n;
-        while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2;
-            if ((sorted[mid].key & kIdMask) <= id) lo = mid + 1;
-            else hi = mid;
-        }
-        return lo;
-    };
-    const uint32_t start = g ? upper_bound(0, g - 1) : 0;
-    const uint32_t end = upper_bound(start, g);
-    const uint32_t main_count = end - start;
-    rt_group_data grp = grp_data[g];
-    grp.base[0] = start;
-    grp.base[1] = grp.offset[1] - main_count;
-    const uint32_t total = main_count + grp.count[1];
-    const uint32_t tail = g != groups - 1 ? total % glob->warp_width : total;  // the last group is the dead-ray bin
-    grp.count[0] = total - tail;
-    grp.count[1] = tail;
-    grp_data[g] = grp;
-}
-
-constexpr int kScanThreads = 1024;
-constexpr uint32_t kScanBatch = 8;
-
-// The prefix sums of update_groups (ray-tracer.cl:276-290) as one work-group: each thread owns a
-// contiguous run of groups, the runs are chained by a block-wide exclusive scan of (whole-warp, parked)
-// counts.  Loads are issued in batches so a thread pays one memory latency per batch, not per group.
-__global__ __launch_bounds__(kScanThreads) void k_update_groups(DevGlobal *glob, rt_group_data *grp_data)
-{
-    __shared__ uint2 s_wave[kScanThreads / 64];
-    __shared__ uint2 s_total;
-    const uint32_t n = glob->g.group_count;
+    __shared__ uint2 s_part[kGroupThreads];
+    __shared__ bool s_last;
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n + kScanThreads - 1) / kScanThreads;
-    const uint32_t first = tid * per < n ? tid * per : n, last = first + per < n ? first + per : n;
+    const uint32_t g = blockIdx.x * kGroupThreads + tid;
+    const uint32_t groups = glob->g.group_count, n = glob->g.ray_count;
 
+    // E[id] = number of sorted entries whose group id is <= id, by binary search (the reference marks
+    // boundaries per ray and fills the gaps serially).  Both ends of the group's run are searched in
+    // the same loop, so that their memory latencies overlap.
     uint2 mine = make_uint2(0, 0);
-    for (uint32_t at = first; at < last; at += kScanBatch) {
-        uint2 c[kScanBatch];
-#pragma unroll
-        for (uint32_t k = 0; k < kScanBatch; k++)
-            c[k] = at + k < last ? *reinterpret_cast<const uint2 *>(grp_data[at + k].count) : make_uint2(0, 0);
-#pragma unroll
-        for (uint32_t k = 0; k < kScanBatch; k++) {
-            mine.x += c[k].x;
-            mine.y += c[k].y;
+    GroupMove m = GroupMove{0, 0, 0, 0, 0, {0, 0, 0}};
+    if (g < groups) {
+        uint32_t lo0 = 0, hi0 = g ? n : 0, lo1 = 0, hi1 = n;
+        while (lo0 < hi0 || lo1 < hi1) {
+            const uint32_t mid0 = lo0 + (hi0 - lo0) / 2, mid1 = lo1 + (hi1 - lo1) / 2;
+            const uint32_t k0 = lo0 < hi0 ? sorted[mid0].key & kIdMask : 0;
+            const uint32_t k1 = lo1 < hi1 ? sorted[mid1].key & kIdMask : 0;
+            if (lo0 < hi0) {
+                if (k0 < g) lo0 = mid0 + 1;
+                else hi0 = mid0;
+            }
+            if (lo1 < hi1) {
+                if (k1 <= g) lo1 = mid1 + 1;
+                else hi1 = mid1;
+            }
         }
+        const uint32_t main_count = lo1 - lo0;
+        const rt_group_data grp = grp_data[g];
+        const uint32_t total = main_count + grp.count[1];
+        const uint32_t tail = g != groups - 1 ? total % glob->warp_width : total;  // the last group is the dead-ray bin
+        m.base0 = lo0;
+        m.base1 = grp.offset[1] - main_count;
+        m.count1 = tail;
+        mine = make_uint2(total - tail, tail);
+        *reinterpret_cast<uint2 *>(grp_data[g].base) = make_uint2(m.base0, m.base1);
+        *reinterpret_cast<uint2 *>(grp_data[g].count) = mine;
     }
+
+    // Exclusive prefix sums of (whole-warp, parked) counts inside the block (ray-tracer.cl:276-290).
     uint2 incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -875,54 +874,87 @@ __global__ __launch_bounds__(kScanThreads) void k_update_groups(DevGlobal *glob,
             incl.y += oy;
         }
     }
-    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    if ((tid & 63) == 63) s_part[tid >> 6] = incl;
     __syncthreads();
-    if (tid == 0) {
-        uint2 run = make_uint2(0, 0);
-        for (int w = 0; w < kScanThreads / 64; w++) {
-            const uint2 t = s_wave[w];
-            s_wave[w] = run;
-            run.x += t.x;
-            run.y += t.y;
+    uint2 before = make_uint2(0, 0), block_total = make_uint2(0, 0);
+#pragma unroll
+    for (int w = 0; w < kGroupThreads / 64; w++) {
+        const uint2 t = s_part[w];
+        if ((uint32_t)w < (tid >> 6)) {
+            before.x += t.x;
+            before.y += t.y;
         }
-        s_total = run;
+        block_total.x += t.x;
+        block_total.y += t.y;
+    }
+    if (g < groups) {
+        m.off0 = before.x + incl.x - mine.x;
+        m.off1 = before.y + incl.y - mine.y;
+        ws.move[g] = m;
+    }
+    if (g == 0) ws.block_sums[gridDim.x] = make_uint2(mine.x, 0);  // whole warps of group 0: the next step's new pixels
+
+    // The last block to get here owns the block totals.
+    if (tid == 0) {
+        ws.block_sums[blockIdx.x] = block_total;
+        __threadfence();
+        s_last = atomicAdd(ws.ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    uint2 offset = make_uint2(s_wave[tid >> 6].x + incl.x - mine.x, s_wave[tid >> 6].y + incl.y - mine.y);
-    const uint32_t all_aligned = s_total.x;
-
-    for (uint32_t at = first; at < last; at += kScanBatch) {
-        uint2 c[kScanBatch];
-#pragma unroll
-        for (uint32_t k = 0; k < kScanBatch; k++)
-            c[k] = at + k < last ? *reinterpret_cast<const uint2 *>(grp_data[at + k].count) : make_uint2(0, 0);
-#pragma unroll
-        for (uint32_t k = 0; k < kScanBatch; k++) {
-            if (at + k < last) *reinterpret_cast<uint2 *>(grp_data[at + k].offset) = make_uint2(offset.x, offset.y + all_aligned);
-            offset.x += c[k].x;
-            offset.y += c[k].y;
+    if (!s_last) return;
+    __threadfence();
+    const uint32_t blocks = gridDim.x;
+    uint2 carry = make_uint2(0, 0);
+    for (uint32_t first = 0; first < blocks; first += kGroupThreads) {  // one round up to 65,536 groups
+        const uint2 sum = first + tid < blocks ? ws.block_sums[first + tid] : make_uint2(0, 0);
+        s_part[tid] = sum;
+        __syncthreads();
+        for (uint32_t off = 1; off < kGroupThreads; off <<= 1) {
+            const uint2 other = tid >= off ? s_part[tid - off] : make_uint2(0, 0);
+            __syncthreads();
+            s_part[tid].x += other.x;
+            s_part[tid].y += other.y;
+            __syncthreads();
         }
+        const uint2 upto = s_part[tid], all = s_part[kGroupThreads - 1];
+        if (first + tid < blocks) ws.block_sums[first + tid] = make_uint2(carry.x + upto.x - sum.x, carry.y + upto.y - sum.y);
+        carry.x += all.x;
+        carry.y += all.y;
+        __syncthreads();
     }
     if (tid == 0) {
         glob->g.pixel_offset += glob->g.pixel_count;
-        glob->g.pixel_count = grp_data[0].count[0];
-        glob->g.old_count = glob->g.ray_count;
-        glob->g.ray_count = all_aligned;
-        glob->spill_count = 0;  // the next step's overflow list starts empty
+        glob->g.pixel_count = ws.block_sums[blocks].x;
+        glob->g.old_count = n;
+        glob->g.ray_count = carry.x;  // all whole warps; the parked rays follow them
+        glob->spill_count = 0;        // the next step's overflow list starts empty
+        *ws.ticket = 0;
     }
 }
 
 // set_ray_index (ray-tracer.cl:293-302)
-__global__ void k_set_ray_index(const DevGlobal *glob, const rt_group_data *grp_data, const rt_index_pair *src,
-                                rt_index_pair *dst, uint32_t count)
+__global__ __launch_bounds__(kGroupThreads) void k_set_ray_index(const DevGlobal *glob, rt_group_data *grp_data,
+                                                                  CompactWorkspace ws, const rt_index_pair *src,
+                                                                  rt_index_pair *dst, uint32_t count, uint32_t group_blocks)
 {
-    uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t all_aligned = glob->g.ray_count;
+    if (blockIdx.x < group_blocks) {  // finished offsets of this block's groups (ray-tracer.cl:283-289)
+        const uint32_t g = blockIdx.x * kGroupThreads + threadIdx.x;
+        if (g >= glob->g.group_count) return;
+        const GroupMove m = ws.move[g];
+        const uint2 block = ws.block_sums[blockIdx.x];
+        *reinterpret_cast<uint2 *>(grp_data[g].offset) = make_uint2(block.x + m.off0, all_aligned + block.y + m.off1);
+        return;
+    }
+    uint32_t index = (blockIdx.x - group_blocks) * kGroupThreads + threadIdx.x;
     if (index >= count) return;
     const rt_index_pair e = src[index];
-    const rt_group_data grp = grp_data[e.key & kIdMask];
-    index -= (index < glob->g.old_count ? grp.base[0] : grp.base[1]);
-    if (index < grp.count[1]) index += grp.offset[1];
-    else index += grp.offset[0] - grp.count[1];
+    const uint32_t g = e.key & kIdMask;
+    const GroupMove m = ws.move[g];
+    const uint2 block = ws.block_sums[g / kGroupThreads];
+    index -= index < glob->g.old_count ? m.base0 : m.base1;
+    if (index < m.count1) index += all_aligned + block.y + m.off1;
+    else index += block.x + m.off0 - m.count1;
     if (index < count) dst[index] = e;  // always true for consistent group data; keeps bad caller data from faulting
 }
 
@@ -979,7 +1011,7 @@ void launch_process_boxes(const LaunchCtx &c)
 void launch_process_leaves(const LaunchCtx &c, hipStream_t stream)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    k_process_mesh<<<grid_for(c.pool, 256), 256, 0, stream>>>(a);
+    k_process_mesh<<<grid_for(c.pool, kMeshThreads), kMeshThreads, 0, stream>>>(a);
 }
 
 void launch_process_shade(const LaunchCtx &c)
@@ -990,15 +1022,18 @@ void launch_process_shade(const LaunchCtx &c)
 
 void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst)
 {
-    launch_compact_raw(c.stream, c.frame.glob, c.grp_data, sorted, dst, c.pool, c.group_count);
+    launch_compact_raw(c.stream, c.frame.glob, c.grp_data, c.compact, sorted, dst, c.pool, c.group_count);
 }
 
-void launch_compact_raw(hipStream_t stream, DevGlobal *glob, rt_group_data *grp_data, const rt_index_pair *sorted,
-                        rt_index_pair *dst, uint32_t count, uint32_t group_count)
+uint32_t compact_group_blocks(uint32_t group_count) { return grid_for(group_count, kGroupThreads).x; }
+
+void launch_compact_raw(hipStream_t stream, DevGlobal *glob, rt_group_data *grp_data, const CompactWorkspace &ws,
+                        const rt_index_pair *sorted, rt_index_pair *dst, uint32_t count, uint32_t group_count)
 {
-    k_count_groups<<<grid_for(group_count, 256), 256, 0, stream>>>(glob, grp_data, sorted);
-    k_update_groups<<<1, kScanThreads, 0, stream>>>(glob, grp_data);
-    k_set_ray_index<<<grid_for(count, 256), 256, 0, stream>>>(glob, grp_data, sorted, dst, count);
+    const uint32_t group_blocks = compact_group_blocks(group_count);
+    k_count_groups<<<group_blocks, kGroupThreads, 0, stream>>>(glob, grp_data, sorted, ws);
+    k_set_ray_index<<<group_blocks + grid_for(count, kGroupThreads).x, kGroupThreads, 0, stream>>>(glob, grp_data, ws, sorted, dst,
+                                                                                                 count, group_blocks);
 }
 
 void launch_resolve(const LaunchCtx &c, void *out)

@@ -12,6 +12,7 @@ struct LaunchCtx {
     rt_camera cam;
     rt_group_data *grp_data;
     SpillEntry *spill_list;  // pool / 64 entries: waves with rays whose box visit overflowed the main kernel
+    CompactWorkspace compact;
     uint32_t pool, area_size, group_count;
 };
 
@@ -23,8 +24,9 @@ void launch_process_boxes(const LaunchCtx &c);
 void launch_process_leaves(const LaunchCtx &c, hipStream_t stream);
 void launch_process_shade(const LaunchCtx &c);
 void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst);
-void launch_compact_raw(hipStream_t stream, DevGlobal *glob, rt_group_data *grp_data, const rt_index_pair *sorted,
-                        rt_index_pair *dst, uint32_t count, uint32_t group_count);
+void launch_compact_raw(hipStream_t stream, DevGlobal *glob, rt_group_data *grp_data, const CompactWorkspace &ws,
+                        const rt_index_pair *sorted, rt_index_pair *dst, uint32_t count, uint32_t group_count);
+uint32_t compact_group_blocks(uint32_t group_count);  // block_sums holds this many entries + 1
 void launch_resolve(const LaunchCtx &c, void *out_dev);
 void launch_export_rays(const LaunchCtx &c, rt_ray_queue *out_dev);
 
