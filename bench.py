@@ -10,7 +10,9 @@ main.cpp:268-343) at 1920x1080 with a pool of 2,080,768 ray slots per GPU; drago
 shipped, so a generated stand-in mesh of the same size takes its place.  With N > 1 (one process per
 GPU, launched by torch.distributed.run) the frame is split into N row bands, the scene is replicated,
 every GPU keeps a full-size pool (weak scaling) and the resolved RGBA8 bands are all-gathered with
-RCCL once per frame, inside the timed region.
+RCCL once per frame, inside the timed region.  The timed region is K steps plus one resolve of the
+frame into device memory (the reference resolves into a GL texture, main.cpp:479-490); the cost of
+also copying the frame to host memory is reported separately (frame_resolve_to_host_ms).
 
 Rank 0 prints ONE JSON line.  `value` is measured over K steps of the production schedule (the leaf
 kernel on a second stream beside the box and shading kernels, no events between kernels).  `roofline`
@@ -153,7 +155,7 @@ def main():
                 band[:rows] = torch.from_numpy(host_band)
             dist.all_gather(list(frame.unbind(0)), band)
         else:
-            rt.draw_frame(host_band)
+            rt.draw_frame_device()  # the image stays on the device, as the reference's stays in its GL texture
 
     def barrier():
         rt.sync()
@@ -170,6 +172,9 @@ def main():
     resolve_and_gather()
     barrier()
     gather_ms = (time.perf_counter() - t_g) * 1e3  # one resolve + gather, measured outside the timed region too
+    t_h = time.perf_counter()
+    rt.draw_frame(host_band)                       # the same resolve plus the copy of the band to host memory
+    readback_ms = (time.perf_counter() - t_h) * 1e3
     keys = ("primary_spawned", "shadow_spawned", "box_tests", "tri_tests")
     c0 = rt.counters()
     rt.set_profiling(1 if args.stage_timers == "timed" else 0)
@@ -251,6 +256,7 @@ def main():
                        "warp_width": args.warp_width, "groups": sc.group_count},
             "mrays_primary_only": float(total[1]) / elapsed / 1e6,
             "stage_ms_per_step": per_launch, "stage_timers": args.stage_timers, "frame_resolve_gather_ms": gather_ms,
+            "frame_resolve_to_host_ms": readback_ms,
             "roofline": roof[0], "roofline_other_bound": roof[1],
         }
         if world == 1 and args.cpu_seconds > 0:

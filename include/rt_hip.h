@@ -164,8 +164,12 @@ int rt_set_warp_width(rt_ctx *ctx, uint32_t warp_width);
 int rt_sync(rt_ctx *ctx);
 
 /* Replaces draw_frame + update_image (main.cpp:479-490, ray-tracer.cl:305-309): RGBA8, row-major,
- * width*height*4 bytes.  dst is a host pointer, or a device pointer when dst_is_device != 0. */
+ * width*height*4 bytes.  dst is a host pointer, or a device pointer when dst_is_device != 0; with
+ * dst == NULL and dst_is_device != 0 the image stays in the context's own device buffer
+ * (rt_image_device), as the reference's stays in its GL texture. */
 int rt_resolve_rgba8(rt_ctx *ctx, void *dst, int dst_is_device);
+/* Device address of the context's RGBA8 image (width*height*4 bytes), valid until rt_destroy. */
+void *rt_image_device(rt_ctx *ctx);
 
 /* Reads the float4 accumulator `area` (main.cpp:349) to host memory, width*height*4 floats. */
 int rt_read_area(rt_ctx *ctx, float *dst);

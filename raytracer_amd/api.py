@@ -19,7 +19,7 @@ EXPORTS = (
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_init_frame", "rt_step", "rt_set_warp_width", "rt_sync",
     "rt_resolve_rgba8", "rt_read_area", "rt_current_ray", "rt_get_global", "rt_get_counters", "rt_sort_pairs",
     "rt_compact_groups", "rt_dump_state", "rt_read_hits", "rt_trace_closest", "rt_set_profiling",
-    "rt_get_stage_times", "rt_debug_stamps", "rt_stream", "rt_status_string", "rt_last_error",
+    "rt_get_stage_times", "rt_debug_stamps", "rt_image_device", "rt_stream", "rt_status_string", "rt_last_error",
 )
 
 
@@ -68,6 +68,7 @@ def hip_lib():
             "rt_set_profiling": (i, [vp, i]),
             "rt_get_stage_times": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
             "rt_debug_stamps": (i, [vp, C.POINTER(C.c_uint64), i]),
+            "rt_image_device": (vp, [vp]),
             "rt_stream": (vp, [vp]),
             "rt_status_string": (C.c_char_p, [i]),
             "rt_last_error": (C.c_char_p, [vp]),
@@ -137,8 +138,12 @@ class RayTracer:
         self._check(self.lib.rt_resolve_rgba8(self.h, out.ctypes.data, 0))
         return out
 
-    def draw_frame_device(self, device_ptr):
-        self._check(self.lib.rt_resolve_rgba8(self.h, C.c_void_p(device_ptr), 1))
+    def draw_frame_device(self, device_ptr=None):
+        """Resolves into device memory: the caller's buffer, or the context's own image (image_device)."""
+        self._check(self.lib.rt_resolve_rgba8(self.h, C.c_void_p(device_ptr) if device_ptr else None, 1))
+
+    def image_device(self):
+        return self.lib.rt_image_device(self.h)
 
     def current_ray(self):
         v = C.c_uint32()

@@ -527,9 +527,9 @@ int rt_sync(rt_ctx *c)
 
 int rt_resolve_rgba8(rt_ctx *c, void *dst, int dst_is_device)
 {
-    if (!c || !dst) return RT_ERR_INVALID_VALUE;
+    if (!c || (!dst && !dst_is_device)) return RT_ERR_INVALID_VALUE;
     RT_HIP(c, hipSetDevice(c->cfg.device));
-    launch_resolve(launch_ctx(c), dst_is_device ? dst : c->rgba);
+    launch_resolve(launch_ctx(c), dst_is_device && dst ? dst : c->rgba);
     int rc = check_launch(c, "resolve");
     if (rc) return rc;
     if (!dst_is_device) RT_HIP(c, hipMemcpyAsync(dst, c->rgba, size_t(c->area_size) * 4, hipMemcpyDeviceToHost, c->stream));
@@ -788,6 +788,11 @@ int rt_debug_stamps(rt_ctx *c, uint64_t dst[8], int reset)
         RT_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RT_OK;
+}
+
+void *rt_image_device(rt_ctx *c)
+{
+    return c ? static_cast<void *>(c->rgba) : nullptr;
 }
 
 void *rt_stream(rt_ctx *c)

@@ -92,6 +92,16 @@ def test_finished_frame_golden(bunny_scene_64):
     assert H.same_bytes(rt.hits(), g["hits"])                                    # ids exact, t exact
     assert np.allclose(rt.area(), g["area"], rtol=1e-5, atol=1e-6)              # colour sums
     assert np.abs(rt.draw_frame().astype(int) - g["image"].astype(int)).max() <= 1  # 1 LSB at 8 bit
+    # the same image resolved into the context's own device buffer
+    import ctypes
+    host = rt.draw_frame()
+    rt.draw_frame_device()
+    back = np.zeros_like(host)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert rt.image_device()
+    assert hip.hipMemcpy(back.ctypes.data, rt.image_device(), back.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+    assert np.array_equal(back, host)
     c = rt.counters()
     gc = g["counters"][0]
     assert int(c["primary_spawned"]) == limit == int(gc["primary_spawned"])
