@@ -55,6 +55,21 @@ def test_state_matches_oracle_with_second_model(standin_ply):
     rt.close(); o.close()
 
 
+def test_more_than_65536_groups():
+    """70 separately built models: 72,704 groups, so the sort takes a third 8-bit pass and the
+    compaction more than one round of block sums."""
+    from oracle import pyoracle as O
+    sc = S.build_scene([S.BUNNY] * 70, 128, 128, 16384, n_obj=140)
+    assert sc.group_count > 65536
+    rt = api.RayTracer(sc, warp_width=32)
+    o = O.Oracle(sc, warp_width=32)
+    rt.init_frame(); o.init_frame()
+    for chunk in range(5):
+        rt.make_step(8); o.step(8)
+        assert_same_state(rt, o, chunk)
+    rt.close(); o.close()
+
+
 def test_pipeline_golden_state(bunny_scene_128):
     g = np.load(os.path.join(GOLDEN, "pipeline_bunny128.npz"))
     rt = api.RayTracer(bunny_scene_128, warp_width=int(g["warp_width"]), hit_capacity=len(g["hits"]))
