@@ -58,6 +58,9 @@ def parse():
                    help="after: the timed steps run the production schedule untouched and the per-kernel HIP events are "
                         "taken over the same number of steps right after them, kernels serialised; timed: events inside "
                         "the timed steps (costs about 9% and the leaf span overlaps the other two)")
+    p.add_argument("--serial", action="store_true",
+                   help="keep every kernel of a step on one stream (as the stage-timing pass does): a rocprofv3 summary "
+                        "of this run shows each kernel's duration alone")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo gathers through host memory: a rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     return p.parse_args()
@@ -132,6 +135,8 @@ def main():
             dist.init_process_group("gloo")
     tensor_device = "cuda" if args.backend == "nccl" else "cpu"
 
+    if args.serial:
+        os.environ["RT_NO_OVERLAP"] = "1"  # read by rt_create
     files, label = model_files(args, rank)
     first, rows = tiling.band_of(rank, world, args.height)
     pool = S.L.align_up(args.width * args.height, S.L.SORT_TILE)
@@ -255,7 +260,7 @@ def main():
                        "tiling": f"{world} row band(s), RGBA8 all-gather per frame" if world > 1 else "single GPU",
                        "warp_width": args.warp_width, "groups": sc.group_count},
             "mrays_primary_only": float(total[1]) / elapsed / 1e6,
-            "stage_ms_per_step": per_launch, "stage_timers": args.stage_timers, "frame_resolve_gather_ms": gather_ms,
+            "stage_ms_per_step": per_launch, "stage_timers": args.stage_timers, "schedule": "serial" if args.serial else "leaf kernel on a second stream", "frame_resolve_gather_ms": gather_ms,
             "frame_resolve_to_host_ms": readback_ms,
             "roofline": roof[0], "roofline_other_bound": roof[1],
         }
