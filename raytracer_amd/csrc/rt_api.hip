@@ -297,7 +297,11 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
         RT_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
     RT_HIP(c, dev_alloc(c->glob, 1));
+#if defined(RT_STAMPS) && RT_STAMPS == 3
+    RT_HIP(c, dev_alloc(c->counters, size_t(kCounterShards) * kCounterKinds + size_t(c->pool / 64) * 4));  // + per-wave trace
+#else
     RT_HIP(c, dev_alloc(c->counters, size_t(kCounterShards) * kCounterKinds));
+#endif
     RT_HIP(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * kCounterShards * kCounterKinds, c->stream));
     RT_HIP(c, dev_alloc(c->area, c->area_size));
     RT_HIP(c, dev_alloc(c->rays, c->pool));
@@ -780,6 +784,9 @@ int rt_debug_stamps(rt_ctx *c, uint64_t dst[8], int reset)
     const int rc = read_counters(c, sums, false);
     if (rc) return rc;
     for (int k = 0; k < 8; k++) dst[k] = k < 4 ? sums[4 + k] : 0;
+#if defined(RT_STAMPS) && RT_STAMPS == 3
+    dst[7] = reinterpret_cast<uint64_t>(c->counters + size_t(kCounterShards) * kCounterKinds);  // device address of the wave trace
+#endif
     if (reset) {
         // only the stamp half of every shard is cleared; the event counters keep running
         std::vector<unsigned long long> zero(4, 0);

@@ -665,9 +665,19 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, Sp
     const uint32_t tid = threadIdx.x;
     const uint32_t index = blockIdx.x * blockDim.x + tid;
     DevGlobal *glob = a.frame.glob;
-    if (index >= glob->g.ray_count) return;
+#if defined(RT_STAMPS) && RT_STAMPS == 3
+    unsigned long long trace_t0;
+    uint32_t trace_hw, trace_xcc;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t0)::"memory");
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(trace_hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(trace_xcc));
+    unsigned long long *trace = a.frame.counters + size_t(kCounterShards) * kCounterKinds + (size_t(blockIdx.x) * (kAabbThreads / 64) + tid / 64) * 4;
+    if ((tid & 63) == 0) { trace[0] = trace_t0; trace[1] = 0; trace[2] = ((unsigned long long)trace_xcc << 32) | trace_hw; trace[3] = 0; }
+#endif
+    // the grid covers the pool exactly: the entry is requested before the live count has arrived
     const rt_index_pair entry = a.frame.index[index];
     const uint32_t key = entry.key;
+    if (index >= glob->g.ray_count) return;
     if (((key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) != RT_SH_AABB) return;
     RaySlot *ray = &a.frame.rays[entry.slot];
 
@@ -685,6 +695,14 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, Sp
     const unsigned long long spilled = __ballot(!done);
     if (spilled && lane_id() == (uint32_t)(__ffsll((long long)spilled) - 1))
         spill_list[atomicAdd(&glob->spill_count, 1u)] = SpillEntry{spilled, index & ~63u, 0u};
+#if defined(RT_STAMPS) && RT_STAMPS == 3
+    {
+        unsigned long long trace_t1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t1)::"memory");
+        const unsigned long long m_ = __ballot(true);
+        if (lane_id() == (uint32_t)(__ffsll((long long)m_) - 1)) { trace[1] = trace_t1; trace[3] = key; }
+    }
+#endif
 }
 
 // The rays the main kernel could not finish: one wave per entry of the hand-over list.  Runs as the
@@ -721,9 +739,9 @@ __device__ __forceinline__ void process_aabb_big(const ProcessArgs &a, const Spi
 __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
 {
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= a.frame.glob->g.ray_count) return;
-    const rt_index_pair entry = a.frame.index[index];
+    const rt_index_pair entry = a.frame.index[index];  // requested before the live count has arrived
     const uint32_t key = entry.key;
+    if (index >= a.frame.glob->g.ray_count) return;
     if (((key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) != RT_SH_MESH) return;
     RaySlot *ray = &a.frame.rays[entry.slot];
 
