@@ -58,6 +58,9 @@ def parse():
                    help="after: the timed steps run the production schedule untouched and the per-kernel HIP events are "
                         "taken over the same number of steps right after them, kernels serialised; timed: events inside "
                         "the timed steps (costs about 9% and the leaf span overlaps the other two)")
+    p.add_argument("--aabb-threshold", type=int, default=128,
+                   help="boxes per inner group of the hierarchy build (the reference builds with 128, main.cpp:290)")
+    p.add_argument("--tri-threshold", type=int, default=128, help="triangles per leaf (the reference builds with 128)")
     p.add_argument("--serial", action="store_true",
                    help="keep every kernel of a step on one stream (as the stage-timing pass does): a rocprofv3 summary "
                         "of this run shows each kernel's duration alone")
@@ -140,7 +143,8 @@ def main():
     files, label = model_files(args, rank)
     first, rows = tiling.band_of(rank, world, args.height)
     pool = S.L.align_up(args.width * args.height, S.L.SORT_TILE)
-    sc = S.build_scene(files, args.width, args.height, pool, band_first=first, band_rows=rows)
+    sc = S.build_scene(files, args.width, args.height, pool, band_first=first, band_rows=rows,
+                       tri_threshold=args.tri_threshold, aabb_threshold=args.aabb_threshold)
     rt = api.RayTracer(sc, device=device, warp_width=args.warp_width)
     rt.init_frame()
 
@@ -258,7 +262,8 @@ def main():
             "config": {"workload": f"{label}, 256 instances (reference scene), {args.width}x{args.height}, "
                                    f"{pool} ray slots per GPU, primary + shadow rays",
                        "tiling": f"{world} row band(s), RGBA8 all-gather per frame" if world > 1 else "single GPU",
-                       "warp_width": args.warp_width, "groups": sc.group_count},
+                       "warp_width": args.warp_width, "groups": sc.group_count,
+                       "tri_threshold": args.tri_threshold, "aabb_threshold": args.aabb_threshold},
             "mrays_primary_only": float(total[1]) / elapsed / 1e6,
             "stage_ms_per_step": per_launch, "stage_timers": args.stage_timers, "schedule": "serial" if args.serial else "leaf kernel on a second stream", "frame_resolve_gather_ms": gather_ms,
             "frame_resolve_to_host_ms": readback_ms,
