@@ -840,23 +840,48 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
 // its group's block offset on the fly; its first blocks write the finished offsets into the group
 // table.  No workgroup waits for another one.
 
+constexpr uint32_t kCoarseKeys = 1024;
+
 // count_groups (ray-tracer.cl:235-253) + update_groups (:255-290)
 __global__ __launch_bounds__(kGroupThreads) void k_count_groups(DevGlobal *glob, rt_group_data *grp_data,
                                                                  const rt_index_pair *sorted, CompactWorkspace ws)
 {
     __shared__ uint2 s_part[kGroupThreads];
+    __shared__ uint32_t s_coarse[kCoarseKeys];
     __shared__ bool s_last;
     const uint32_t tid = threadIdx.x;
     const uint32_t g = blockIdx.x * kGroupThreads + tid;
     const uint32_t groups = glob->g.group_count, n = glob->g.ray_count;
 
     // E[id] = number of sorted entries whose group id is <= id, by binary search (the reference marks
-    // boundaries per ray and fills the gaps serially).  Both ends of the group's run are searched in
-    // the same loop, so that their memory latencies overlap.
+    // boundaries per ray and fills the gaps serially).  The first ten steps of every search run on a
+    // table of every stride-th key held in LDS, the rest on the list itself; both ends of the group's
+    // run are searched in the same loop, so that their memory latencies overlap.
+    uint32_t stride = 1;
+    while ((n + stride - 1) / stride > kCoarseKeys) stride *= 2;
+    const uint32_t samples = (n + stride - 1) / stride;  // s_coarse[j] = id of entry j * stride
+    for (uint32_t j = tid; j < samples; j += kGroupThreads) s_coarse[j] = sorted[j * stride].key & kIdMask;
+    __syncthreads();
     uint2 mine = make_uint2(0, 0);
     GroupMove m = GroupMove{0, 0, 0, 0, 0, {0, 0, 0}};
     if (g < groups) {
-        uint32_t lo0 = 0, hi0 = g ? n : 0, lo1 = 0, hi1 = n;
+        // upper_bound on the samples: entries before sample number c are known to be <= id, the answer
+        // lies in ((c - 1) * stride, c * stride]
+        auto narrow = [&](bool inclusive, uint32_t id, uint32_t &lo, uint32_t &hi) {
+            uint32_t a = 0, b = samples;
+            while (a < b) {
+                const uint32_t mid = a + (b - a) / 2;
+                const uint32_t key = s_coarse[mid];
+                if (inclusive ? key <= id : key < id) a = mid + 1;
+                else b = mid;
+            }
+            lo = a ? (a - 1) * stride + 1 : 0;
+            hi = a * stride < n ? a * stride : n;
+            if (!a) hi = 0;
+        };
+        uint32_t lo0 = 0, hi0 = 0, lo1, hi1;
+        if (g) narrow(false, g, lo0, hi0);
+        narrow(true, g, lo1, hi1);
         while (lo0 < hi0 || lo1 < hi1) {
             const uint32_t mid0 = lo0 + (hi0 - lo0) / 2, mid1 = lo1 + (hi1 - lo1) / 2;
             const uint32_t k0 = lo0 < hi0 ? sorted[mid0].key & kIdMask : 0;
