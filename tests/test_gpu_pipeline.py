@@ -242,3 +242,31 @@ def test_headline_size_properties(standin_ply):
     img = rt.draw_frame()
     assert img.shape == (1080, 1920, 4) and img[..., :3].max() > 100
     rt.close()
+
+
+def test_cpp_host_renders_the_same_frame(tmp_path, bunny_scene_128):
+    """The C++ host (raytracer_amd/host/rt_main: scene build, class RayTracer, frame loop) over the C ABI
+    against the Python plumbing on the same scene: one frame of 32 steps."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracer_amd", "host", "rt_main")
+    assert os.path.exists(exe), "run `make host` (or __graft_entry__.build())"
+    out = str(tmp_path / "frame.ppm")
+    run = subprocess.run([exe, "--width", "128", "--height", "128", "--rays", "16384", "--frames", "1", "--steps", "32",
+                          "--warp", "32", "--models", S.BUNNY + ";" + S.BUNNY, "--out", out],
+                         cwd=root, capture_output=True, text=True, timeout=240)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Frame ready in" in run.stdout
+    with open(out, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = map(int, f.readline().split())
+        assert f.readline().strip() == b"255"
+        ppm = np.frombuffer(f.read(), np.uint8).reshape(h, w, 3)
+    rt = api.RayTracer(bunny_scene_128, warp_width=32)
+    rt.init_frame()
+    rt.make_step(32)
+    image = rt.draw_frame()
+    rt.close()
+    assert (w, h) == (128, 128)
+    # the PPM is written bottom row first (the reference displays its texture with y up)
+    assert np.abs(ppm.astype(int) - image[::-1, :, :3].astype(int)).max() <= 1
