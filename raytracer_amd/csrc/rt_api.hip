@@ -35,6 +35,8 @@ struct rt_ctx {
     CompactWorkspace compact = {nullptr, nullptr, nullptr};
     uchar4 *rgba = nullptr;
     SortWorkspace ws{};
+    hipGraphExec_t step_graph = nullptr;  // one step (both streams), captured on first use; dropped when its arguments change
+    bool use_graph = true;
 
     rt_group *grp = nullptr;
     rt_matrix *mat = nullptr;
@@ -132,8 +134,15 @@ hipError_t alloc_compact(CompactWorkspace &ws, uint32_t group_count)
     return err;
 }
 
+void drop_step_graph(rt_ctx *c)
+{
+    if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
+    c->step_graph = nullptr;
+}
+
 void free_scene(rt_ctx *c)
 {
+    drop_step_graph(c);
     dev_free(c->grp);
     dev_free(c->mat);
     dev_free(c->aabb);
@@ -291,6 +300,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
 
     RT_HIP(c, hipSetDevice(cfg->device));
     RT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->use_graph = getenv("RT_NO_GRAPH") == nullptr;
     if (!getenv("RT_NO_OVERLAP")) {
         RT_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         RT_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -505,8 +515,30 @@ int rt_step(rt_ctx *c, uint32_t n_steps)
     if (!c->frame_ready) return fail(c, RT_ERR_NOT_READY, "rt_step before rt_init_frame");
     RT_HIP(c, hipSetDevice(c->cfg.device));
     for (uint32_t s = 0; s < n_steps; s++) {
-        const int rc = one_step(c, true);
-        if (rc) return rc;
+        // Every launch of a step has the same arguments from step to step (the counts that change live
+        // in device memory), so the step is captured once, fork and join of the second stream
+        // included, and replayed: the dependencies between its kernels then cost less than events
+        // recorded from the host.
+        if (c->use_graph && !c->profiling) {
+            if (!c->step_graph) {
+                hipGraph_t graph = nullptr;
+                RT_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                const int rc = one_step(c, true);
+                const hipError_t ended = hipStreamEndCapture(c->stream, &graph);
+                if (rc) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    return rc;
+                }
+                RT_HIP(c, ended);
+                const hipError_t made = hipGraphInstantiate(&c->step_graph, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                RT_HIP(c, made);
+            }
+            RT_HIP(c, hipGraphLaunch(c->step_graph, c->stream));
+        } else {
+            const int rc = one_step(c, true);
+            if (rc) return rc;
+        }
         c->steps++;
     }
     return RT_OK;
