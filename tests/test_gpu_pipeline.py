@@ -55,6 +55,26 @@ def test_state_matches_oracle_with_second_model(standin_ply):
     rt.close(); o.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_stage_timers_do_not_change_the_state(bunny_scene_128, mode):
+    """With stage timing on, rt_step launches its kernels one by one (mode 2: on one stream) instead of
+    replaying the captured step; the state must be the oracle's either way, and every stage gets a time."""
+    from oracle import pyoracle as O
+    rt = api.RayTracer(bunny_scene_128, warp_width=32)
+    o = O.Oracle(bunny_scene_128, warp_width=32)
+    rt.init_frame(); o.init_frame()
+    rt.make_step(4); o.step(4)          # captured step
+    rt.set_profiling(mode)
+    rt.make_step(12); o.step(12)        # separate launches with events
+    times, steps = rt.stage_times()
+    assert steps == 12 and set(times) == set(api.STAGE_NAMES)
+    assert all(ms > 0 for ms in times.values())
+    rt.set_profiling(0)
+    rt.make_step(4); o.step(4)          # captured step again
+    assert_same_state(rt, o, mode)
+    rt.close(); o.close()
+
+
 def test_more_than_65536_groups():
     """70 separately built models: 72,704 groups, so the sort takes a third 8-bit pass and the
     compaction more than one round of block sums."""
