@@ -9,18 +9,21 @@
 //     constant address space, while each lane keeps its own ray in VGPRs;
 //   * a wave that does hold several groups (unaligned tails, drain mode) peels them off one at a time
 //     (`while (todo) { g = readfirstlane(key); ... }`), so the kernels are correct for any order;
-//   * the up-to-64 candidate boxes of a visit live in LDS as [entry][thread] columns: any per-lane
-//     entry index maps lane -> bank (tid mod 32), conflict-free for 4-byte accesses;
+//   * the candidate boxes of a visit live in LDS as [entry][thread] columns: any per-lane entry index
+//     maps lane -> bank (tid mod 32), conflict-free for 4-byte accesses; the main box kernel keeps 24
+//     per lane, the rare visits that need the reference's 64 are handed over to a second body;
 //   * the pending-node queue of a ray is merged straight into its slot in HBM from a register
 //     snapshot of the old entries -- no scratch memory;
 //   * box groups, leaf groups and shader groups run as three kernels with different register/LDS
-//     budgets, the box kernel first; both read the step's keys from `index` and write the new ones to `next`, so
-//     a ray advanced by one kernel is never picked up again by the other in the same step.
+//     budgets; all read the step's keys from `index` and write the new ones to `next`, so a ray
+//     advanced by one kernel is never picked up again by another in the same step, and the leaf
+//     kernel can run beside the other two.
 #include "rt_device.h"
 
 namespace rtd {
 
-// Phase stamps of diagnostic builds: -DRT_STAMPS=1 times the box-group kernel, =2 the leaf/shading kernel.
+// Phase stamps of diagnostic builds: -DRT_STAMPS=1 times the box-group kernel, =2 the leaf and shading
+// kernels, =3 records start and end of every wave of the box kernel.
 #if defined(RT_STAMPS) && RT_STAMPS == 1
 #define AABB_STAMP(v) RT_STAMP(v)
 #define AABB_STAMP_ADD(f, s, a, b) RT_STAMP_ADD(f, s, a, b)
