@@ -56,7 +56,7 @@ struct alignas(16) DevGlobal {
                                                     // spill_count: rays queued for the large box-visit kernel
 };
 
-// Hand-over of one wave's unfinished box visits from the main kernel to the large-list kernel.
+// Hand-over of one wave's unfinished box visits from the box kernel to the body with the large candidate list.
 struct SpillEntry {
     unsigned long long lanes;  // which of the 64 positions starting at `first`
     uint32_t first, pad;

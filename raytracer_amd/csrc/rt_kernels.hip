@@ -447,10 +447,11 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
 // ---------------------------------------------------------------- process, box groups
 // aabb_shader (shader.cl:76-101) + insert_hits (ray-tracer.cl:90-117, 205-231)
 //
-// Two kernels share one body.  More than 16 accepted boxes in a visit are rare (3 visits in 10,000 on
+// Two bodies share one visit function.  More than 16 accepted boxes in a visit are rare (3 visits in 10,000 on
 // the benchmark scene, 5 in a million more than 24), so the main kernel keeps 24 candidates per lane in LDS (30 KB per block:
 // occupancy is then 5 waves per SIMD instead of 2); a lane that accepts a 25th box leaves its ray
-// untouched and queues it for the second kernel, which has room for the reference's 64 candidates.
+// untouched and queues it for the second body (process_aabb_big, run inside the shading launch), which
+// has room for the reference's 64 candidates.
 
 #ifndef RT_AABB_THREADS
 #define RT_AABB_THREADS 256
@@ -461,7 +462,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
 constexpr int kAabbThreads = RT_AABB_THREADS;  // main kernel
 constexpr int kMeshThreads = RT_MESH_THREADS;
 constexpr int kAabbCap = 24;
-constexpr int kBigThreads = 64;    // overflow kernel: one wave per block
+constexpr int kBigThreads = 64;    // handed-over visits: one wave per workgroup
 constexpr int kBigBlocks = 256;
 
 // One box against one ray: entry and exit parameter of the slab test (shader.cl:86-91).
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, Sp
     }
     if (done) a.frame.next[index] = rt_index_pair{new_key, entry.slot};
     // Rare: lanes that need the large candidate list.  They are handed over wave by wave (first
-    // position + lane mask), so that the second kernel sees them grouped exactly as they are here.
+    // position + lane mask), so that the second body sees them grouped exactly as they are here.
     const unsigned long long spilled = __ballot(!done);
     if (spilled && lane_id() == (uint32_t)(__ffsll((long long)spilled) - 1))
         spill_list[atomicAdd(&glob->spill_count, 1u)] = SpillEntry{spilled, index & ~63u, 0u};
