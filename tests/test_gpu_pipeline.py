@@ -190,6 +190,32 @@ def test_trace_closest_matches_oracle_and_brute_force(bunny_scene_64):
     rt.close(); o.close()
 
 
+def test_incoherent_rays_in_a_grid_of_instances(standin_ply):
+    """The shape of the incoherent workload: a regular 4x4x4 grid of instances of two models, rays with
+    random origins inside the grid and random directions; hits bit-exact against the oracle."""
+    from oracle import pyoracle as O
+    sc = S.build_scene([S.BUNNY, standin_ply], 64, 64, 65536, grid=4)
+    root = int(sc.data["cam"]["root_group"][0]) & L.GROUP_ID_MASK
+    first, count = int(sc.groups["w"][root][0]), int(sc.groups["w"][root][1])
+    assert count == 64
+    boxes = sc.aabbs[first:first + count]
+    lo, hi = boxes["min"].min(axis=0), boxes["max"].max(axis=0)
+    rng = np.random.default_rng(5)
+    n = 40000
+    rays = np.zeros(n, L.ray_dtype)
+    rays["start_min"][:, :3] = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    rays["start_min"][:, 3] = 0.001
+    d = rng.normal(size=(n, 3))
+    rays["dir_max"][:, :3] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["dir_max"][:, 3] = np.inf
+    rt = api.RayTracer(sc, warp_width=64)
+    o = O.Oracle(sc, warp_width=32, threads=8)
+    got, want = rt.trace_closest(rays), o.trace_closest(rays)
+    assert H.same_bytes(got, want)
+    assert 0.01 < np.isfinite(got["t"]).mean() < 1.0
+    rt.close(); o.close()
+
+
 def test_api_errors(bunny_scene_64):
     rt = api.RayTracer(bunny_scene_64)
     with pytest.raises(api.RtError, match="RT_ERR_NOT_READY"):
