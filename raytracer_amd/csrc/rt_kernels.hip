@@ -447,11 +447,12 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
 // ---------------------------------------------------------------- process, box groups
 // aabb_shader (shader.cl:76-101) + insert_hits (ray-tracer.cl:90-117, 205-231)
 //
-// Two bodies share one visit function.  More than 16 accepted boxes in a visit are rare (3 visits in 10,000 on
-// the benchmark scene, 5 in a million more than 24), so the main kernel keeps 24 candidates per lane in LDS (30 KB per block:
-// occupancy is then 5 waves per SIMD instead of 2); a lane that accepts a 25th box leaves its ray
-// untouched and queues it for the second body (process_aabb_big, run inside the shading launch), which
-// has room for the reference's 64 candidates.
+// Two bodies share one visit function.  More than 16 accepted boxes in a visit are rare (3 visits in
+// 10,000 on the benchmark scene, 5 in a million more than 24, the maximum seen is 36), so the main kernel
+// keeps 16 candidates per lane in LDS (20 KB per block of 256) and holds the pending queue entries in
+// registers only after the scan: seven waves per SIMD instead of the two that 64 candidates would
+// allow.  A lane that accepts a 17th box leaves its ray untouched and queues it for the second body
+// (process_aabb_big, run inside the shading launch), which has room for the reference's 64 candidates.
 
 #ifndef RT_AABB_THREADS
 #define RT_AABB_THREADS 256
@@ -461,7 +462,13 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
 #endif
 constexpr int kAabbThreads = RT_AABB_THREADS;  // main kernel
 constexpr int kMeshThreads = RT_MESH_THREADS;
-constexpr int kAabbCap = 24;
+#ifndef RT_AABB_CAP
+#define RT_AABB_CAP 16
+#endif
+#ifndef RT_AABB_WAVES
+#define RT_AABB_WAVES 7  // waves per SIMD the box kernel is compiled for (72 registers)
+#endif
+constexpr int kAabbCap = RT_AABB_CAP;
 constexpr int kBigThreads = 64;    // handed-over visits: one wave per workgroup
 constexpr int kBigBlocks = 256;
 
@@ -486,21 +493,12 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     AABB_STAMP(t_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
     const uint32_t count = grp.y;
-    // Everything this visit needs from the ray slot is requested now, so that the box scan covers the
-    // latency: the slot's first 128-byte line (meta, ray, queue[0..4]) without conditions, the rest
-    // of the queue only if it is that long.  No load is issued once the stores of the merge begin.
+    // What the scan needs from the slot (meta, ray, head of the queue: its first 64 bytes) is requested
+    // now.  No load is issued once the stores of the merge begin.
     const uint4 meta = *reinterpret_cast<const uint4 *>(ray);  // pixel, type, material_id, queue_len
     const float4 sm = ray->start_min, dm = ray->dir_max;
     const uint32_t old_len = meta.w;
-    RayHit q[RT_MAX_QUEUE_LEN];
-#pragma unroll
-    for (int i = 0; i < 5; i++) q[i] = ray->queue[i];
-#pragma unroll
-    for (int i = 5; i < RT_MAX_QUEUE_LEN; i++) {
-        q[i] = RayHit{0.0f, 0u, 0u, 0u};
-        if ((uint32_t)i < old_len) q[i] = ray->queue[i];
-    }
-    const RayHit head = q[0];
+    const RayHit head = ray->queue[0];
     const LocalRay lr = make_local(g, sm, dm, head.local0, a.scene.mat);
     const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
     if (!BIG) count_lanes(a.frame, kBoxTests, true, count);
@@ -559,6 +557,16 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     if (spill) {
         if (!BIG) return false;
         n = 0;  // more than 64 candidates: the reference gives up on the whole node
+    }
+    // The pending entries are fetched only now (two visits in three have none): held across the scan
+    // they would cost 28 registers, i.e. two of the seven waves a SIMD holds of this kernel.  The hit
+    // network below covers most of their latency.
+    RayHit q[RT_MAX_QUEUE_LEN];
+    q[0] = head;
+#pragma unroll
+    for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
+        q[i] = RayHit{0.0f, 0u, 0u, 0u};
+        if ((uint32_t)i < old_len) q[i] = ray->queue[i];
     }
 
     // sort_hits (ray-tracer.cl:90-117): the reference's compare-exchange network, run with
@@ -661,6 +669,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     return true;
 }
 
+__attribute__((amdgpu_waves_per_eu(RT_AABB_WAVES, 8)))
 __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, SpillEntry *spill_list)
 {
     __shared__ float s_pos[kAabbCap][kAabbThreads];
@@ -740,6 +749,9 @@ __device__ __forceinline__ void process_aabb_big(const ProcessArgs &a, const Spi
 // ---------------------------------------------------------------- process, everything but box groups
 
 // Leaf groups: triangle scan + hit commit.
+#ifdef RT_MESH_WAVES
+__attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, 8)))
+#endif
 __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
 {
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
