@@ -320,20 +320,11 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
 {
     MISC_STAMP(t_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // vtx_offs, tri_offs, tri_count, material_id
-    // The slot's first 128-byte line (meta, ray, queue[0..4]) is requested at once and the rest of the
-    // queue if it is that long, so that the triangle scan covers the latency.
+    // What the scan needs from the slot (meta, ray, head of the queue) is requested at once.
     const uint4 meta = *reinterpret_cast<const uint4 *>(ray);  // pixel, type, material_id, queue_len
     const float4 sm = ray->start_min, dm = ray->dir_max;
     const uint32_t queue_len = meta.w;
-    RayHit q[RT_MAX_QUEUE_LEN];
-#pragma unroll
-    for (int i = 0; i < 5; i++) q[i] = ray->queue[i];
-#pragma unroll
-    for (int i = 5; i < RT_MAX_QUEUE_LEN; i++) {
-        q[i] = RayHit{0.0f, 0u, 0u, 0u};
-        if ((uint32_t)i < queue_len) q[i] = ray->queue[i];
-    }
-    const RayHit head = q[0];
+    const RayHit head = ray->queue[0];
     const LocalRay lr = make_local(g, sm, dm, head.local0, a.scene.mat);
 
     count_lanes(a.frame, kTriTests, true, grp.z);
@@ -390,6 +381,14 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     // Miss: pop the head (ray-tracer.cl:154-165).  Hit: insert_stop (ray-tracer.cl:173-203).  What a
     // hit still needs from memory (shading normal, sample id, or the shadow weight) is loaded before
     // the first store of this visit.
+    // The pending entries are fetched only now: held across the scan they would cost 28 registers.
+    RayHit q[RT_MAX_QUEUE_LEN];
+    q[0] = head;
+#pragma unroll
+    for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
+        q[i] = RayHit{0.0f, 0u, 0u, 0u};
+        if ((uint32_t)i < queue_len) q[i] = ray->queue[i];
+    }
     const bool hit = hit_index != 0xFFFFFFFFu, shadow = meta.y == RT_RAY_SHADOW;
     uint32_t len = queue_len - 1, end_group = meta.z, sid = 0xFFFFFFFFu;
     float shadow_weight = 0;
@@ -467,6 +466,9 @@ constexpr int kMeshThreads = RT_MESH_THREADS;
 #endif
 #ifndef RT_AABB_WAVES
 #define RT_AABB_WAVES 7  // waves per SIMD the box kernel is compiled for (72 registers)
+#endif
+#ifndef RT_MESH_WAVES
+#define RT_MESH_WAVES 7  // the same for the leaf kernel
 #endif
 constexpr int kAabbCap = RT_AABB_CAP;
 constexpr int kBigThreads = 64;    // handed-over visits: one wave per workgroup
@@ -749,9 +751,7 @@ __device__ __forceinline__ void process_aabb_big(const ProcessArgs &a, const Spi
 // ---------------------------------------------------------------- process, everything but box groups
 
 // Leaf groups: triangle scan + hit commit.
-#ifdef RT_MESH_WAVES
 __attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, 8)))
-#endif
 __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
 {
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
