@@ -31,3 +31,12 @@ def standin_ply(tmp_path_factory):
     from raytracer_amd import scene as S
     path = str(tmp_path_factory.mktemp("models") / "standin_small.ply")
     return S.write_standin_ply(path, 264, 132)
+
+
+@pytest.fixture(scope="session")
+def standin_full_ply(tmp_path_factory):
+    """The full-size dragon stand-in: 870,488 triangles, the hierarchy shape of dragon_vrip.ply
+    (model root of 64 boxes, 64 inner groups of 128, 8,192 leaves)."""
+    from raytracer_amd import scene as S
+    path = str(tmp_path_factory.mktemp("models") / "standin_full.ply")
+    return S.write_standin_ply(path, 934, 466)
