@@ -192,6 +192,19 @@ int rt_get_counters(rt_ctx *ctx, rt_counters *dst);
 int rt_sort_pairs(rt_ctx *ctx, const rt_index_pair *in, rt_index_pair *out,
                   uint32_t count, uint32_t n, uint32_t group_count, int on_device);
 
+/* The sort of rt_sort_pairs (device pointers) for callers that cannot allocate device memory: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in
+ * the reference and needs no rt_ctx: its pass workspace is a fixed array of 8.1 MB inside the library's
+ * device image (each GPU the library runs on holds it until the process ends), so the call performs no
+ * hipMalloc/hipFree.  in_dev/out_dev are device pointers on the CURRENT device, must not overlap, and
+ * the kernels are enqueued on `stream` (a hipStream_t of that device, NULL = the default stream).
+ * count must be a multiple of RT_SORT_TILE and at most RT_SORT_STATIC_MAX_PAIRS (RT_ERR_UNSUPPORTED
+ * beyond).  All calls on one GPU share that GPU's workspace: calls that may overlap in time on the
+ * same GPU (different streams or threads) race and must be serialised by the caller. */
+#define RT_SORT_STATIC_MAX_PAIRS 1048576u
+int rt_sort_pairs_static(const rt_index_pair *in_dev, rt_index_pair *out_dev,
+                         uint32_t count, uint32_t n, uint32_t group_count, void *stream);
+
 /* Replaces count_groups + update_groups + set_ray_index (ray-tracer.cl:235-302; main.cpp:464-472)
  * for one call on caller data (host pointers): `sorted` holds count pairs, the first
  * global->ray_count of them sorted; grp_data holds global->group_count entries and is updated in

@@ -19,7 +19,7 @@ EXPORTS = (
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_init_frame", "rt_step", "rt_set_warp_width", "rt_sync",
     "rt_resolve_rgba8", "rt_read_area", "rt_current_ray", "rt_get_global", "rt_get_counters", "rt_sort_pairs",
     "rt_compact_groups", "rt_dump_state", "rt_read_hits", "rt_trace_closest", "rt_set_profiling",
-    "rt_get_stage_times", "rt_debug_stamps", "rt_image_device", "rt_stream", "rt_status_string", "rt_last_error",
+    "rt_get_stage_times", "rt_debug_stamps", "rt_sort_pairs_static", "rt_image_device", "rt_stream", "rt_status_string", "rt_last_error",
 )
 
 
@@ -61,6 +61,7 @@ def hip_lib():
             "rt_get_global": (i, [vp, vp]),
             "rt_get_counters": (i, [vp, vp]),
             "rt_sort_pairs": (i, [vp, vp, vp, u32, u32, u32, i]),
+            "rt_sort_pairs_static": (i, [vp, vp, u32, u32, u32, vp]),
             "rt_compact_groups": (i, [vp, vp, vp, u32, vp, vp, u32]),
             "rt_dump_state": (i, [vp, vp, vp, vp]),
             "rt_read_hits": (i, [vp, vp, u32, u32]),

@@ -299,6 +299,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
     *out = c;  // so that rt_last_error / rt_destroy work on a half-built context
 
     RT_HIP(c, hipSetDevice(cfg->device));
+    RT_HIP(c, sort_static_setup(nullptr));  // rt_sort_pairs_static's workspace on this device
     RT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->use_graph = getenv("RT_NO_GRAPH") == nullptr;
     if (!getenv("RT_NO_OVERLAP")) {

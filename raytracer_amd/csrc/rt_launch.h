@@ -41,5 +41,7 @@ struct SortWorkspace {
 void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pair *in, rt_index_pair *out,
                  uint32_t count, const uint32_t *n_dev, uint32_t group_count);
 uint32_t sort_key_bits(uint32_t group_count);
+// Looks up the workspace of rt_sort_pairs_static on the current device (once per device; allocates nothing).
+hipError_t sort_static_setup(void **out);
 
 }  // namespace rtd

@@ -10,6 +10,8 @@
 //   * the scatter stages its tile in LDS (in logical, i.e. thread-major, order on the first pass),
 //     ranks 64 keys at a time with wave ballots (match-any on the digit) against per-wave LDS
 //     counters, orders the tile in LDS and writes each digit's run to HBM contiguously.
+#include <mutex>
+
 #include "rt_launch.h"
 
 namespace rtd {
@@ -241,3 +243,85 @@ void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pai
 }
 
 }  // namespace rtd
+
+// ---------------------------------------------------------------- the sort without any allocation
+//
+// rt_sort_pairs_static: the same kernels, with the pass workspace (live count, per-digit totals, per-tile
+// digit counts, ping-pong buffer) in a file-scope device array instead of buffers a context allocated.
+// Every GPU holds its own copy of the array at its own address; that address is looked up once per
+// device and only the looked-up pointer is ever handed to a kernel or a copy.
+
+namespace {
+
+constexpr uint32_t kStaticMaxPairs = RT_SORT_STATIC_MAX_PAIRS;
+constexpr uint32_t kStaticMaxTiles = kStaticMaxPairs / rtd::kTile;
+static_assert(kStaticMaxPairs % rtd::kTile == 0, "the static limit is a whole number of tiles");
+
+struct StaticSortScratch {
+    uint32_t n;                                        // live count of the call in flight
+    uint32_t pad[63];
+    uint32_t totals[rtd::kRadix];
+    uint32_t counts[rtd::kRadix * kStaticMaxTiles];
+    rt_index_pair tmp[kStaticMaxPairs];
+};
+
+// 8.1 MB per GPU, held until the process ends.  In host code this name is only a handle for
+// hipGetSymbolAddress; it is not a device address.
+static __device__ __align__(256) unsigned char scratch[sizeof(StaticSortScratch)];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_lock;
+StaticSortScratch *g_scratch_ptr[kMaxDevices];  // device address of `scratch` on each GPU, once looked up
+
+__global__ void k_store_u32(uint32_t *dst, uint32_t value)
+{
+    *dst = value;
+}
+
+}  // namespace
+
+namespace rtd {
+
+// Looks up, once per device, where `scratch` lives on the CURRENT device.  Called by rt_create for the
+// context's device and by rt_sort_pairs_static on first use.  Allocates nothing.
+hipError_t sort_static_setup(void **out)
+{
+    int device = -1;
+    hipError_t err = hipGetDevice(&device);
+    if (err != hipSuccess) return err;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> guard(g_scratch_lock);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (err != hipSuccess) return err;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<StaticSortScratch *>(ptr);
+    }
+    if (out) *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
+}  // namespace rtd
+
+extern "C" int rt_sort_pairs_static(const rt_index_pair *in_dev, rt_index_pair *out_dev, uint32_t count, uint32_t n,
+                                    uint32_t group_count, void *stream)
+{
+    if (!in_dev || !out_dev || !count || count % RT_SORT_TILE) return RT_ERR_INVALID_VALUE;
+    if (count > kStaticMaxPairs) return RT_ERR_UNSUPPORTED;  // beyond the static workspace: use rt_sort_pairs
+    if (n > count || !group_count || group_count > RT_GROUP_ID_MASK + 1) return RT_ERR_INVALID_VALUE;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(in_dev), b = reinterpret_cast<uintptr_t>(out_dev);
+    const uintptr_t bytes = uintptr_t(count) * sizeof(rt_index_pair);
+    if (a < b + bytes && b < a + bytes) return RT_ERR_INVALID_VALUE;  // in and out overlap
+    void *where = nullptr;
+    if (rtd::sort_static_setup(&where) != hipSuccess) return RT_ERR_HIP;
+    StaticSortScratch *ws = static_cast<StaticSortScratch *>(where);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // Nothing in the workspace has to start at zero: every pass overwrites the counts of the tiles it
+    // reads and all totals before using them, and tmp is written before it is read.
+    k_store_u32<<<1, 1, 0, s>>>(&ws->n, n);
+    const rtd::SortWorkspace sw{ws->counts, ws->totals, ws->tmp, count / RT_SORT_TILE};
+    rtd::launch_sort(s, sw, in_dev, out_dev, count, &ws->n, group_count);
+    return hipGetLastError() == hipSuccess ? RT_OK : RT_ERR_LAUNCH;
+}
+
