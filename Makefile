@@ -42,7 +42,7 @@ clean:
 	rm -f $(CSRC)/librt_hip.so $(HOST)/librt_host.so $(HOST)/rt_main
 	$(MAKE) -C oracle clean
 
-.PHONY: all device host oracle clean stamps variant
+.PHONY: all device host oracle clean stamps variant resources
 
 # Diagnostic build with per-phase cycle stamps in the kernels (never loaded by default; RT_HIP_LIB selects it).
 stamps: $(CSRC)/librt_hip_stamps1.so $(CSRC)/librt_hip_stamps2.so $(CSRC)/librt_hip_stamps3.so
@@ -52,3 +52,8 @@ $(CSRC)/librt_hip_stamps%.so: $(HIP_SOURCES) $(HIP_HEADERS)
 # Experimental build with extra defines: make variant NAME=x DEFS="-DRT_AABB_THREADS=64" -> librt_hip_var_x.so
 variant:
 	$(HIPCC) $(HIPFLAGS) $(DEFS) $(HIP_SOURCES) -o $(CSRC)/librt_hip_var_$(NAME).so
+
+# Register, scratch and LDS use of every kernel (compiler remarks), e.g. `make resources | less`.
+resources:
+	@for f in $(HIP_SOURCES); do $(HIPCC) $(filter-out -shared,$(HIPFLAGS)) $(DEFS) --cuda-device-only -c -Rpass-analysis=kernel-resource-usage $$f -o /dev/null 2>&1 | \
+	  grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | sed -e 's/.*remark: //' | paste - - - - - - ; done

@@ -30,8 +30,8 @@ struct rt_ctx {
     RaySlot *rays = nullptr;
     rt_index_pair *index = nullptr, *next = nullptr, *sorted = nullptr;
     rt_hit_record *hits = nullptr;
+    uint32_t *spill_list = nullptr;
     rt_group_data *grp_data = nullptr;
-    SpillEntry *spill_list = nullptr;
     CompactWorkspace compact = {nullptr, nullptr, nullptr};
     uchar4 *rgba = nullptr;
     SortWorkspace ws{};
@@ -322,7 +322,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
     RT_HIP(c, dev_alloc(c->ws.tmp, c->pool));
     RT_HIP(c, dev_alloc(c->hits, cfg->hit_capacity));
     RT_HIP(c, dev_alloc(c->rgba, c->area_size));
-    RT_HIP(c, dev_alloc(c->spill_list, c->pool / 64));
+    RT_HIP(c, dev_alloc(c->spill_list, c->pool));
     c->ws.tiles = c->pool / RT_SORT_TILE;
     RT_HIP(c, dev_alloc(c->ws.counts, size_t(256) * c->ws.tiles));
     RT_HIP(c, dev_alloc(c->ws.totals, 256));

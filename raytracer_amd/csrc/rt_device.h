@@ -53,13 +53,7 @@ struct alignas(16) DevGlobal {
     rt_global_data g;
     uint32_t warp_width, sample_limit, hit_capacity, row_offset;
     uint32_t mode, sort_count, spill_count, pad1;  // sort_count: element count for stand-alone sort calls;
-                                                    // spill_count: rays queued for the large box-visit kernel
-};
-
-// Hand-over of one wave's unfinished box visits from the box kernel to the body with the large candidate list.
-struct SpillEntry {
-    unsigned long long lanes;  // which of the 64 positions starting at `first`
-    uint32_t first, pad;
+                                                    // spill_count: box visits left to k_process_aabb_big this step
 };
 
 // Queue compaction: what moving an entry of group g needs, and the per-block prefix sums.

@@ -10,8 +10,8 @@
 //   * a wave that does hold several groups (unaligned tails, drain mode) peels them off one at a time
 //     (`while (todo) { g = readfirstlane(key); ... }`), so the kernels are correct for any order;
 //   * the candidate boxes of a visit live in LDS as [entry][thread] columns: any per-lane entry index
-//     maps lane -> bank (tid mod 32), conflict-free for 4-byte accesses; the main box kernel keeps 24
-//     per lane, the rare visits that need the reference's 64 are handed over to a second body;
+//     maps lane -> bank (tid mod 32), conflict-free for 4-byte accesses; the box kernel keeps 16 per
+//     lane, the rare visit that needs the reference's 64 is redone by a whole wave (second kernel);
 //   * the pending-node queue of a ray is merged straight into its slot in HBM from a register
 //     snapshot of the old entries -- no scratch memory;
 //   * box groups, leaf groups and shader groups run as three kernels with different register/LDS
@@ -446,12 +446,11 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
 // ---------------------------------------------------------------- process, box groups
 // aabb_shader (shader.cl:76-101) + insert_hits (ray-tracer.cl:90-117, 205-231)
 //
-// Two bodies share one visit function.  More than 16 accepted boxes in a visit are rare (3 visits in
-// 10,000 on the benchmark scene, 5 in a million more than 24, the maximum seen is 36), so the main kernel
-// keeps 16 candidates per lane in LDS (20 KB per block of 256) and holds the pending queue entries in
-// registers only after the scan: seven waves per SIMD instead of the two that 64 candidates would
-// allow.  A lane that accepts a 17th box leaves its ray untouched and queues it for the second body
-// (process_aabb_big, run inside the shading launch), which has room for the reference's 64 candidates.
+// More than 16 accepted boxes in a visit are rare (3 visits in 10,000 on the benchmark scene, 5 in a
+// million more than 24, the maximum seen is 36), so the kernel keeps 16 candidates per lane in LDS
+// (20 KB per block of 256) and holds the pending queue entries in registers only after the scan: seven
+// waves per SIMD instead of the two that 64 candidates per lane would allow.  A lane that accepts a
+// 17th box leaves its ray untouched; k_process_aabb_big redoes that visit with a whole wave.
 
 #ifndef RT_AABB_THREADS
 #define RT_AABB_THREADS 256
@@ -471,26 +470,96 @@ constexpr int kMeshThreads = RT_MESH_THREADS;
 #define RT_MESH_WAVES 7  // the same for the leaf kernel
 #endif
 constexpr int kAabbCap = RT_AABB_CAP;
-constexpr int kBigThreads = 64;    // handed-over visits: one wave per workgroup
-constexpr int kBigBlocks = 256;
 
 // One box against one ray: entry and exit parameter of the slab test (shader.cl:86-91).
-__device__ __forceinline__ bool box_test(const f32x8 b, const LocalRay &lr, const V3 inv_dir, float &t_entry)
+__device__ __forceinline__ bool box_test(const f32x8 b, const V3 start, const V3 inv_dir, float ray_min, float ray_max,
+                                         float &t_entry)
 {
-    const V3 pos1 = (v3(b.s0, b.s1, b.s2) - lr.start) * inv_dir;
-    const V3 pos2 = (v3(b.s4, b.s5, b.s6) - lr.start) * inv_dir;
+    const V3 pos1 = (v3(b.s0, b.s1, b.s2) - start) * inv_dir;
+    const V3 pos2 = (v3(b.s4, b.s5, b.s6) - start) * inv_dir;
     const float t_min = fmaxf(fmaxf(fminf(pos1.x, pos2.x), fminf(pos1.y, pos2.y)), fminf(pos1.z, pos2.z));
     const float t_max = fminf(fminf(fmaxf(pos1.x, pos2.x), fmaxf(pos1.y, pos2.y)), fmaxf(pos1.z, pos2.z));
-    t_entry = fmaxf(t_min, lr.tmin);
-    return t_max > t_min && t_max > lr.tmin && t_min < lr.tmax;
+    t_entry = fmaxf(t_min, ray_min);
+    return t_max > t_min && t_max > ray_min && t_min < ray_max;
 }
 
-// One visit of box group g (wave-uniform) by this lane's ray.  CAP = candidates kept per lane; with
-// BIG the reference's limit applies (a 65th candidate empties the list, shader.cl:93), otherwise a
-// lane that needs more than CAP returns false without having changed its ray.
-template <int CAP, int THREADS, bool BIG>
+__device__ __forceinline__ float lane_value(float v, uint32_t lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)lane));
+}
+
+// The rare visit that accepts more than the per-lane columns hold (the reference allows 64 candidates,
+// shader.cl:93): the whole wave works on ONE ray.  Every active lane tests a share of the group's
+// boxes, accepted boxes are appended in list order (ballot + prefix count, as the reference's loop
+// appends them), and the reference's compare-exchange network (ray-tracer.cl:90-117) runs with one
+// lane per exchange: all exchanges of one inner loop of the network touch disjoint pairs.  c_pos/c_idx
+// are this wave's 64-entry scratch lists in LDS.  Returns the candidate count (0 when more than 64
+// boxes are accepted: the reference gives up on the whole node), the list is left sorted.
+__device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t count, const V3 start, const V3 inv_dir,
+                                                   float ray_min, float ray_max, float *c_pos, uint8_t *c_idx)
+{
+    const unsigned long long active = __ballot(true);
+    const unsigned long long below = (1ull << lane_id()) - 1;
+    const uint32_t rank = __popcll(active & below), workers = __popcll(active);
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < count; base += workers) {
+        const uint32_t i = base + rank;
+        bool hit = false;
+        float t = 0;
+        if (i < count) {
+            const float4 lo = *reinterpret_cast<const float4 *>(list[i].min), hi = *reinterpret_cast<const float4 *>(list[i].max);
+            f32x8 b;
+            b.s0 = lo.x;  b.s1 = lo.y;  b.s2 = lo.z;  b.s3 = lo.w;
+            b.s4 = hi.x;  b.s5 = hi.y;  b.s6 = hi.z;  b.s7 = hi.w;
+            hit = box_test(b, start, inv_dir, ray_min, ray_max, t);
+        }
+        const unsigned long long m = __ballot(hit);
+        const uint32_t at = total + __popcll(m & below);
+        if (hit && at < RT_MAX_HITS) {
+            c_pos[at] = t;
+            c_idx[at] = (uint8_t)i;
+        }
+        total += __popcll(m);
+    }
+    if (total > RT_MAX_HITS) return 0;
+    auto exchange = [&](uint32_t j, uint32_t i) {
+        const float pj = c_pos[j], pi = c_pos[i];
+        if (pj > pi) {
+            const uint8_t ij = c_idx[j], ii = c_idx[i];
+            c_pos[j] = pi;  c_pos[i] = pj;
+            c_idx[j] = ii;  c_idx[i] = ij;
+        }
+    };
+    for (uint32_t base = 1; base < total; base *= 2) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = rank; i < total; i += workers)
+            if (i >= base && (i & base)) exchange(i - 2 * (i & (base - 1)) - 1, i);
+        for (uint32_t offs = base / 2; offs; offs /= 2) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t i = rank; i < total; i += workers)
+                if (i >= offs && (i & offs)) exchange(i - offs, i);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return total;
+}
+
+// One visit of box group g (wave-uniform) by this lane's ray.  CAP = candidates kept per lane in the
+// LDS columns s_pos/s_idx.  With COOP false, a lane that accepts more than CAP boxes returns false
+// without having changed its ray.  With COOP true the whole wave performs the visit of ONE ray (the
+// caller hands every lane that ray's group and slot): the scan and the candidate sort are done by
+// wave_visit_one in the wave's lists c_pos/c_idx with the reference's limit of 64 candidates, and
+// only the lane `owner` merges and stores.
+template <int CAP, int THREADS, bool COOP>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
-                                           uint8_t (*s_idx)[THREADS], uint32_t tid, uint32_t &new_key)
+                                           uint8_t (*s_idx)[THREADS], float *c_pos, uint8_t *c_idx, uint32_t owner,
+                                           uint32_t tid, uint32_t &new_key)
 {
     AABB_STAMP(t_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
@@ -503,8 +572,13 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     const RayHit head = ray->queue[0];
     const LocalRay lr = make_local(g, sm, dm, head.local0, a.scene.mat);
     const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
-    if (!BIG) count_lanes(a.frame, kBoxTests, true, count);
+    if (!COOP) count_lanes(a.frame, kBoxTests, true, count);  // a redone visit was counted the first time
 
+    uint32_t n = 0;
+    if (COOP) {
+        n = wave_visit_one(a.scene.aabb + grp.x, count, lr.start, inv_dir, lr.tmin, lr.tmax, c_pos, c_idx);
+        if (lane_id() != owner) return true;
+    } else {
     // Box scan.  The list is wave-uniform and comes through the scalar cache, 64 bytes (two boxes) per
     // load; the device copy of a list starts on a 128-byte boundary, is filled up to a multiple of
     // four with boxes no ray can enter and is followed by readable entries, so four boxes are tested
@@ -512,11 +586,10 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     ConstPtr<f32x16> pair = const_ptr<f32x16>(a.scene.aabb + grp.x);  // per box: min.xyz, group id, max.xyz, local id
     asm volatile("" ::"v"(inv_dir.x), "v"(inv_dir.y), "v"(inv_dir.z), "v"(lr.start.x));
     AABB_STAMP(t_loaded);
-    uint32_t n = 0;
     bool spill = false;
     auto test_pair = [&](const f32x16 p, uint32_t i) {
         float t;
-        const bool hit0 = box_test(p.lo, lr, inv_dir, t);
+        const bool hit0 = box_test(p.lo, lr.start, inv_dir, lr.tmin, lr.tmax, t);
         if (hit0) {
             if (n < CAP) {
                 s_pos[n][tid] = t;
@@ -526,7 +599,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
                 spill = true;
             }
         }
-        const bool hit1 = box_test(p.hi, lr, inv_dir, t);
+        const bool hit1 = box_test(p.hi, lr.start, inv_dir, lr.tmin, lr.tmax, t);
         if (hit1) {
             if (n < CAP) {
                 s_pos[n][tid] = t;
@@ -556,9 +629,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     AABB_STAMP(t_scanned);
     AABB_STAMP_ADD(a.frame, 0, t_start, t_loaded);
     AABB_STAMP_ADD(a.frame, 1, t_loaded, t_scanned);
-    if (spill) {
-        if (!BIG) return false;
-        n = 0;  // more than 64 candidates: the reference gives up on the whole node
+    if (spill) return false;
     }
     // The pending entries are fetched only now (two visits in three have none): held across the scan
     // they would cost 28 registers, i.e. two of the seven waves a SIMD holds of this kernel.  The hit
@@ -573,6 +644,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 
     // sort_hits (ray-tracer.cl:90-117): the reference's compare-exchange network, run with
     // wave-uniform (i, j) so every LDS access has a uniform row; lanes with fewer entries idle.
+    if (!COOP) {
     const uint32_t n_max = wave_max_upto127(n);
     auto exchange = [&](uint32_t j, uint32_t i) {
         if (i < n) {
@@ -590,6 +662,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         for (uint32_t offs = base / 2; offs; offs /= 2)
             for (uint32_t i = offs; i < n_max; i++)
                 if (i & offs) exchange(i - offs, i);
+    }
     }
 
     AABB_STAMP(t_sorted);
@@ -610,8 +683,8 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         cand_pos[j] = INFINITY;
         cand_group[j] = cand_local[j] = 0;
         if ((uint32_t)j < n) {
-            const uint32_t bi = s_idx[j][tid];
-            cand_pos[j] = s_pos[j][tid];
+            const uint32_t bi = COOP ? c_idx[j] : s_idx[j][tid];
+            cand_pos[j] = COOP ? c_pos[j] : s_pos[j][tid];
             cand_group[j] = list[bi].group_id;
             cand_local[j] = list[bi].local_id;
         }
@@ -672,7 +745,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 }
 
 __attribute__((amdgpu_waves_per_eu(RT_AABB_WAVES, 8)))
-__global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, SpillEntry *spill_list)
+__global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, uint32_t *spill_list)
 {
     __shared__ float s_pos[kAabbCap][kAabbThreads];
     __shared__ uint8_t s_idx[kAabbCap][kAabbThreads];
@@ -702,14 +775,23 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, Sp
         if (key != __builtin_amdgcn_readfirstlane(key)) continue;
         todo = false;
         const uint32_t g = uniform_value(key);  // every lane still here holds the same key
-        done = visit_aabb<kAabbCap, kAabbThreads, false>(g, ray, a, s_pos, s_idx, tid, new_key);
+        done = visit_aabb<kAabbCap, kAabbThreads, false>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key);
     }
-    if (done) a.frame.next[index] = rt_index_pair{new_key, entry.slot};
-    // Rare: lanes that need the large candidate list.  They are handed over wave by wave (first
-    // position + lane mask), so that the second body sees them grouped exactly as they are here.
+    // Rare (3 visits in 10,000 on the benchmark scene): lanes whose columns overflowed and whose rays are
+    // therefore untouched.  Their positions go to a list (one atomic per wave); k_process_aabb_big
+    // performs those visits with one wave per ray.
     const unsigned long long spilled = __ballot(!done);
-    if (spilled && lane_id() == (uint32_t)(__ffsll((long long)spilled) - 1))
-        spill_list[atomicAdd(&glob->spill_count, 1u)] = SpillEntry{spilled, index & ~63u, 0u};
+    if (spilled) {
+        uint32_t base = 0;
+        const uint32_t leader = (uint32_t)(__ffsll((long long)spilled) - 1);
+        if (lane_id() == leader) base = atomicAdd(&glob->spill_count, (uint32_t)__popcll(spilled));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+        if (!done) {
+            spill_list[base + __popcll(spilled & ((1ull << lane_id()) - 1))] = index;
+            return;
+        }
+    }
+    a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 #if defined(RT_STAMPS) && RT_STAMPS == 3
     {
         unsigned long long trace_t1;
@@ -720,31 +802,27 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, Sp
 #endif
 }
 
-// The rays the main kernel could not finish: one wave per entry of the hand-over list.  Runs as the
-// first kBigBlocks workgroups of k_process_shade (first wave of each), i.e. beside the shading
-// work instead of as a launch of its own: a lone wave scanning a 256-box list takes about 50 us, which
-// nothing would hide at the end of a launch.
-__device__ __forceinline__ void process_aabb_big(const ProcessArgs &a, const SpillEntry *spill_list,
-                                                 float (*s_pos)[kBigThreads], uint8_t (*s_idx)[kBigThreads])
+// The box visits the main kernel left undone, one wave per ray: a lone lane scanning a 256-box list and
+// sorting 30 candidates in its own columns takes about 50 us, a wave sharing the work a few.
+constexpr int kBigThreads = 256, kBigBlocks = 256;
+
+__global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a, const uint32_t *spill_list)
 {
-    const uint32_t tid = threadIdx.x;
+    __shared__ float s_wave_pos[kBigThreads / 64][RT_MAX_HITS];   // per wave: the lists of wave_visit_one
+    __shared__ uint8_t s_wave_idx[kBigThreads / 64][RT_MAX_HITS];
+    const uint32_t tid = threadIdx.x, wave = tid / 64;
     const uint32_t total = a.frame.glob->spill_count;
-    for (uint32_t at = blockIdx.x; at < total; at += kBigBlocks) {
-        const SpillEntry e = spill_list[at];
-        if (!((e.lanes >> tid) & 1)) continue;
-        const uint32_t index = e.first + tid;
+    for (uint32_t at = blockIdx.x * (kBigThreads / 64) + wave; at < total; at += kBigBlocks * (kBigThreads / 64)) {
+        const uint32_t index = spill_list[at];
         const rt_index_pair entry = a.frame.index[index];
-        const uint32_t key = entry.key;
-        RaySlot *ray = &a.frame.rays[entry.slot];
-        uint32_t new_key = key;
-        bool todo = true;
-        while (todo) {
-            if (key != __builtin_amdgcn_readfirstlane(key)) continue;
-            todo = false;
-            const uint32_t g = uniform_value(key);
-            visit_aabb<RT_MAX_HITS, kBigThreads, true>(g, ray, a, s_pos, s_idx, tid, new_key);
-        }
-        a.frame.next[index] = rt_index_pair{new_key, entry.slot};
+        const uint32_t g = uniform_value(entry.key), slot = uniform_value(entry.slot);
+        uint32_t new_key = g;
+        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true>(g, &a.frame.rays[slot], a, nullptr, nullptr, s_wave_pos[wave],
+                                                        s_wave_idx[wave], 0, tid, new_key);
+        if (lane_id() == 0) a.frame.next[index] = rt_index_pair{new_key, slot};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the lists are reused by the wave's next ray
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -775,17 +853,10 @@ __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
     a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 }
 
-// Shader groups (spawn, sky, light, material), parked entries, and -- in the first kBigBlocks
-// workgroups -- the box visits the main box kernel handed over.
-__global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t pool, const SpillEntry *spill_list)
+// Shader groups (spawn, sky, light, material) and parked entries.
+__global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t pool)
 {
-    __shared__ float s_pos[RT_MAX_HITS][kBigThreads];
-    __shared__ uint8_t s_idx[RT_MAX_HITS][kBigThreads];
-    if (blockIdx.x < kBigBlocks) {
-        if (threadIdx.x < kBigThreads) process_aabb_big(a, spill_list, s_pos, s_idx);
-        return;
-    }
-    const uint32_t index = (blockIdx.x - kBigBlocks) * blockDim.x + threadIdx.x;
+    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     const DevGlobal *glob = a.frame.glob;
     if (index >= pool) return;
     const rt_index_pair entry = a.frame.index[index];
@@ -986,7 +1057,7 @@ __global__ __launch_bounds__(kGroupThreads) void k_count_groups(DevGlobal *glob,
         glob->g.pixel_count = ws.block_sums[blocks].x;
         glob->g.old_count = n;
         glob->g.ray_count = carry.x;  // all whole warps; the parked rays follow them
-        glob->spill_count = 0;        // the next step's overflow list starts empty
+        glob->spill_count = 0;        // the next step's list of overflowed box visits starts empty
         *ws.ticket = 0;
     }
 }
@@ -1065,6 +1136,7 @@ void launch_process_boxes(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
     k_process_aabb<<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+    k_process_aabb_big<<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
 }
 
 void launch_process_leaves(const LaunchCtx &c, hipStream_t stream)
@@ -1076,7 +1148,7 @@ void launch_process_leaves(const LaunchCtx &c, hipStream_t stream)
 void launch_process_shade(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    k_process_shade<<<dim3(grid_for(c.pool, 256).x + kBigBlocks), 256, 0, c.stream>>>(a, c.pool, c.spill_list);
+    k_process_shade<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
 }
 
 void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst)

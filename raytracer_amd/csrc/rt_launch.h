@@ -11,15 +11,14 @@ struct LaunchCtx {
     Frame frame;
     rt_camera cam;
     rt_group_data *grp_data;
-    SpillEntry *spill_list;  // pool / 64 entries: waves with rays whose box visit overflowed the main kernel
+    uint32_t *spill_list;  // pool entries: index positions of the box visits left to the one-ray-per-wave kernel
     CompactWorkspace compact;
     uint32_t pool, area_size, group_count;
 };
 
 void launch_init_frame(const LaunchCtx &c);
 void launch_load_rays(const LaunchCtx &c, const rt_ray *rays_dev, uint32_t n_rays);
-// The three process kernels touch disjoint rays; only launch_process_shade depends on another one
-// (it finishes the box visits launch_process_boxes handed over), so leaves may run on another stream.
+// The three process kernels touch disjoint rays, so they may run on different streams.
 void launch_process_boxes(const LaunchCtx &c);
 void launch_process_leaves(const LaunchCtx &c, hipStream_t stream);
 void launch_process_shade(const LaunchCtx &c);

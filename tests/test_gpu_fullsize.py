@@ -21,7 +21,7 @@ def test_full_model_state_matches_oracle(standin_full_ply):
     assert sc.group_count == 9728 and len(sc.triangles) > 900000
     cap = 256 * 144 * 2
     rt = api.RayTracer(sc, warp_width=32, hit_capacity=cap)
-    o = O.Oracle(sc, warp_width=32, hit_capacity=cap, threads=8)
+    o = O.Oracle(sc, warp_width=32, hit_capacity=cap)   # one thread: with more, the oracle's accumulator has the reference's race
     rt.init_frame(); o.init_frame()
     for step in range(48):
         rt.make_step(1); o.step(1)
@@ -41,7 +41,7 @@ def test_full_model_finished_frame_matches_oracle(standin_full_ply):
     sc = S.build_scene([S.BUNNY, standin_full_ply], 256, 144, 40960)
     limit = 256 * 144
     rt = api.RayTracer(sc, warp_width=64, sample_limit=limit, hit_capacity=limit)
-    o = O.Oracle(sc, warp_width=32, sample_limit=limit, hit_capacity=limit, threads=8)
+    o = O.Oracle(sc, warp_width=32, sample_limit=limit, hit_capacity=limit)
     run_to_completion(rt, steps_parked=10)
     oracle_to_completion(o, steps_parked=10)
     assert H.same_bytes(rt.hits(), o.hits)
