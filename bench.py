@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--scene", default="bunny+dragon", choices=["bunny+dragon", "bunny", "dragon"])
     p.add_argument("--warp-width", type=int, default=64)
+    p.add_argument("--schedule", default="free", choices=["free", "reference"],
+                   help="free: RT_FLAG_FREE_SCHEDULE (any processing order, same per-sample results); reference: every "
+                        "step reproduces the reference's make_step state exactly")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 disables it)")
     p.add_argument("--dragon", default=os.environ.get("RT_DRAGON_PLY", ""), help="path to dragon_vrip.ply if available")
     p.add_argument("--stage-timers", default="after", choices=["after", "timed"],
@@ -145,7 +148,7 @@ def main():
     pool = S.L.align_up(args.width * args.height, S.L.SORT_TILE)
     sc = S.build_scene(files, args.width, args.height, pool, band_first=first, band_rows=rows,
                        tri_threshold=args.tri_threshold, aabb_threshold=args.aabb_threshold)
-    rt = api.RayTracer(sc, device=device, warp_width=args.warp_width)
+    rt = api.RayTracer(sc, device=device, warp_width=args.warp_width, free_schedule=args.schedule == "free")
     rt.init_frame()
 
     band = frame = None
@@ -262,7 +265,7 @@ def main():
             "config": {"workload": f"{label}, 256 instances (reference scene), {args.width}x{args.height}, "
                                    f"{pool} ray slots per GPU, primary + shadow rays",
                        "tiling": f"{world} row band(s), RGBA8 all-gather per frame" if world > 1 else "single GPU",
-                       "warp_width": args.warp_width, "groups": sc.group_count,
+                       "warp_width": args.warp_width, "schedule": args.schedule, "groups": sc.group_count,
                        "tri_threshold": args.tri_threshold, "aabb_threshold": args.aabb_threshold},
             "mrays_primary_only": float(total[1]) / elapsed / 1e6,
             "stage_ms_per_step": per_launch, "stage_timers": args.stage_timers, "schedule": "serial" if args.serial else "leaf kernel on a second stream", "frame_resolve_gather_ms": gather_ms,

@@ -120,8 +120,19 @@ typedef struct {
     uint32_t hit_capacity; /* keep rt_hit_record for sample ids < hit_capacity; 0 = none */
     uint32_t row_offset;   /* first image row of this context's band: pixel row y is sampled as row_offset + y,
                               so a band renders the same samples as the full frame (0 for a whole frame) */
-    uint32_t flags;        /* reserved, must be 0 */
+    uint32_t flags;        /* RT_FLAG_* bits; other bits must be 0 */
 } rt_config;
+
+/* rt_config.flags.  RT_FLAG_FREE_SCHEDULE: the context may advance rays in any order.  A ray's path
+ * through the hierarchy depends only on its own state and the scene (process, ray-tracer.cl:119-232),
+ * so every sample's result -- its hit record and what it adds to its pixel -- is the same as with the
+ * reference's schedule; what differs is which slot holds which sample after a given step, i.e.
+ * rt_dump_state no longer equals the reference's buffers step by step.  With the flag set the sort
+ * keeps equal keys in their plain order instead of the reference's thread-major tile order
+ * (sort.cl:26-27), sky/light/material shaders run inside the kernel that empties a ray's queue instead
+ * of as a step of their own, and a finished slot is re-initialised and sent through the scene root in one
+ * launch.  Without it (0) every step reproduces the reference's make_step exactly. */
+#define RT_FLAG_FREE_SCHEDULE 1u
 
 enum {
     RT_OK = 0,

@@ -37,6 +37,7 @@ struct rt_ctx {
     SortWorkspace ws{};
     hipGraphExec_t step_graph = nullptr;  // one step (both streams), captured on first use; dropped when its arguments change
     bool use_graph = true;
+    bool free_schedule = false;  // RT_FLAG_FREE_SCHEDULE
 
     rt_group *grp = nullptr;
     rt_matrix *mat = nullptr;
@@ -108,6 +109,7 @@ LaunchCtx launch_ctx(const rt_ctx *c)
     l.pool = c->pool;
     l.area_size = c->area_size;
     l.group_count = c->group_count;
+    l.free_schedule = c->free_schedule;
     return l;
 }
 
@@ -244,11 +246,13 @@ int one_step(rt_ctx *c, bool run_process)
         if ((rc = timed(c, RT_STAGE_TRAVERSE, c->stream, [&] { launch_process_boxes(l); }))) return rc;
         if ((rc = timed(c, RT_STAGE_LEAVES, leaf_stream, [&] { launch_process_leaves(l, leaf_stream); }))) return rc;
         if (fork) RT_HIP(c, hipEventRecord(c->ev_join, c->side));
-        if ((rc = timed(c, RT_STAGE_SHADE, c->stream, [&] { launch_process_shade(l); }))) return rc;
+        // free schedule: the visiting kernels shade, spawn and carry the parked entries over themselves
+        if (!c->free_schedule && (rc = timed(c, RT_STAGE_SHADE, c->stream, [&] { launch_process_shade(l); }))) return rc;
         if (fork) RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     rc = timed(c, RT_STAGE_SORT, c->stream, [&] {
-        launch_sort(c->stream, c->ws, run_process ? c->next : c->index, c->sorted, c->pool, &c->glob->g.ray_count, c->group_count);
+        launch_sort(c->stream, c->ws, run_process ? c->next : c->index, c->sorted, c->pool, &c->glob->g.ray_count, c->group_count,
+                    c->free_schedule);
     });
     if (rc) return rc;
     if ((rc = timed(c, RT_STAGE_COMPACT, c->stream, [&] { launch_compact(l, c->sorted, c->index); }))) return rc;
@@ -284,7 +288,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
 {
     if (!cfg || !out) return RT_ERR_INVALID_VALUE;
     *out = nullptr;
-    if (!cfg->width || !cfg->height || !cfg->ray_count || cfg->flags) return RT_ERR_INVALID_VALUE;
+    if (!cfg->width || !cfg->height || !cfg->ray_count || (cfg->flags & ~RT_FLAG_FREE_SCHEDULE)) return RT_ERR_INVALID_VALUE;
     if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) return RT_ERR_INVALID_VALUE;
     if (uint64_t(cfg->ray_count) + RT_SORT_TILE > 0x7FFFFFFFull) return RT_ERR_INVALID_VALUE;
     int n_dev = 0;
@@ -293,6 +297,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
 
     rt_ctx *c = new rt_ctx;
     c->cfg = *cfg;
+    c->free_schedule = (cfg->flags & RT_FLAG_FREE_SCHEDULE) != 0;
     if (!c->cfg.warp_width) c->cfg.warp_width = 64;
     c->pool = (cfg->ray_count + RT_SORT_TILE - 1) / RT_SORT_TILE * RT_SORT_TILE;
     c->area_size = cfg->width * cfg->height;

@@ -314,6 +314,26 @@ __device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color)
     return reset_ray(ray, root.group_id, root.local0, root.local1, RT_LIGHT_GROUP);
 }
 
+// Free schedule: a ray whose queue has emptied goes to its end group (sky, light, material or spawn).  The
+// reference spends a step of its own on that group's shader; here the visiting kernel runs it on the
+// spot.  Spawn and the dead-ray bin (shader bits 0) stay keys: a finished slot is re-initialised by the
+// box kernel at the next step, when its position in the sorted index gives it its sample id.
+__device__ __forceinline__ uint32_t run_end_group(uint32_t key, RaySlot *ray, const ProcessArgs &a)
+{
+    const uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
+    if (shader == RT_SH_SPAWN || shader >= RT_SH_AABB) return key;
+    asm volatile("" ::: "memory");  // the shader reads what the visit has just stored to the slot
+    if (a.frame.glob->mode & kModeTraceOnly) {
+        const uint32_t dead = a.group_count - 1;
+        ray->queue[0].group_id = dead;
+        return dead;
+    }
+    if (shader != RT_SH_MATERIAL) return sky_or_light_shader(a, ray, shader == RT_SH_LIGHT);
+    const float4 color = *reinterpret_cast<const float4 *>(a.scene.grp + (key & kIdMask));
+    count_lanes(a.frame, kShadowSpawned, true);
+    return mat_shader(ray, color);
+}
+
 // ---------------------------------------------------------------- leaf visit (shader.cl:115-139, ray-tracer.cl:149-203)
 
 __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const ProcessArgs &a)
@@ -744,6 +764,10 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     return true;
 }
 
+// FREE (free schedule): the kernel also re-initialises finished slots (key 0) as new samples and
+// sends them through the scene root in the same launch, runs end-group shaders on the spot
+// (run_end_group) and carries the parked entries over, so no shading launch is needed.
+template <bool FREE>
 __attribute__((amdgpu_waves_per_eu(RT_AABB_WAVES, 8)))
 __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, uint32_t *spill_list)
 {
@@ -764,10 +788,29 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
 #endif
     // the grid covers the pool exactly: the entry is requested before the live count has arrived
     const rt_index_pair entry = a.frame.index[index];
-    const uint32_t key = entry.key;
-    if (index >= glob->g.ray_count) return;
-    if (((key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) != RT_SH_AABB) return;
+    uint32_t key = entry.key;
+    if (index >= glob->g.ray_count) {
+        if (FREE) a.frame.next[index] = entry;  // parked entry: not processed, carried over
+        return;
+    }
+    uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
+    if (FREE ? shader == RT_SH_MESH : shader != RT_SH_AABB) return;
     RaySlot *ray = &a.frame.rays[entry.slot];
+    if (FREE) {
+        if (key == RT_SPAWN_GROUP) {  // a finished slot: the next sample starts here and visits the root below
+            bool started;
+            key = init_ray(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
+            count_lanes(a.frame, kPrimarySpawned, started);
+            asm volatile("" ::: "memory");  // the visit reads the slot init_ray has just written
+            shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
+        }
+        if (shader != RT_SH_AABB) {
+            // a sample beyond the limit (dead-ray bin), a scene whose root is a leaf, or a shader key left by
+            // rt_init_frame/rt_trace_closest: no box visit
+            a.frame.next[index] = rt_index_pair{run_end_group(key, ray, a), entry.slot};
+            return;
+        }
+    }
 
     uint32_t new_key = key;
     bool done = true, todo = true;
@@ -791,6 +834,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
             return;
         }
     }
+    if (FREE) new_key = run_end_group(new_key, ray, a);
     a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 #if defined(RT_STAMPS) && RT_STAMPS == 3
     {
@@ -806,6 +850,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
 // sorting 30 candidates in its own columns takes about 50 us, a wave sharing the work a few.
 constexpr int kBigThreads = 256, kBigBlocks = 256;
 
+template <bool FREE>
 __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a, const uint32_t *spill_list)
 {
     __shared__ float s_wave_pos[kBigThreads / 64][RT_MAX_HITS];   // per wave: the lists of wave_visit_one
@@ -814,12 +859,17 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
     const uint32_t total = a.frame.glob->spill_count;
     for (uint32_t at = blockIdx.x * (kBigThreads / 64) + wave; at < total; at += kBigBlocks * (kBigThreads / 64)) {
         const uint32_t index = spill_list[at];
-        const rt_index_pair entry = a.frame.index[index];
-        const uint32_t g = uniform_value(entry.key), slot = uniform_value(entry.slot);
+        const uint32_t slot = uniform_value(a.frame.index[index].slot);
+        RaySlot *ray = &a.frame.rays[slot];
+        // the group the ray is in: the key of its index entry, except for a sample the box kernel has just started
+        const uint32_t g = uniform_value(ray->queue[0].group_id);
         uint32_t new_key = g;
-        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true>(g, &a.frame.rays[slot], a, nullptr, nullptr, s_wave_pos[wave],
-                                                        s_wave_idx[wave], 0, tid, new_key);
-        if (lane_id() == 0) a.frame.next[index] = rt_index_pair{new_key, slot};
+        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true>(g, ray, a, nullptr, nullptr, s_wave_pos[wave], s_wave_idx[wave], 0, tid,
+                                                        new_key);
+        if (lane_id() == 0) {
+            if (FREE) new_key = run_end_group(new_key, ray, a);
+            a.frame.next[index] = rt_index_pair{new_key, slot};
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // the lists are reused by the wave's next ray
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -829,6 +879,7 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
 // ---------------------------------------------------------------- process, everything but box groups
 
 // Leaf groups: triangle scan + hit commit.
+template <bool FREE>
 __attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, 8)))
 __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
 {
@@ -850,6 +901,7 @@ __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
         MISC_STAMP(t_mesh1);
         MISC_STAMP_ADD(a.frame, 2, t_mesh0, t_mesh1);
     }
+    if (FREE) new_key = run_end_group(new_key, ray, a);
     a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 }
 
@@ -1135,14 +1187,20 @@ void launch_load_rays(const LaunchCtx &c, const rt_ray *rays, uint32_t n_rays)
 void launch_process_boxes(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    k_process_aabb<<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
-    k_process_aabb_big<<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
+    if (c.free_schedule) {
+        k_process_aabb<true><<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+        k_process_aabb_big<true><<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
+    } else {
+        k_process_aabb<false><<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+        k_process_aabb_big<false><<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
+    }
 }
 
 void launch_process_leaves(const LaunchCtx &c, hipStream_t stream)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    k_process_mesh<<<grid_for(c.pool, kMeshThreads), kMeshThreads, 0, stream>>>(a);
+    if (c.free_schedule) k_process_mesh<true><<<grid_for(c.pool, kMeshThreads), kMeshThreads, 0, stream>>>(a);
+    else k_process_mesh<false><<<grid_for(c.pool, kMeshThreads), kMeshThreads, 0, stream>>>(a);
 }
 
 void launch_process_shade(const LaunchCtx &c)

@@ -14,6 +14,7 @@ struct LaunchCtx {
     uint32_t *spill_list;  // pool entries: index positions of the box visits left to the one-ray-per-wave kernel
     CompactWorkspace compact;
     uint32_t pool, area_size, group_count;
+    bool free_schedule;  // RT_FLAG_FREE_SCHEDULE: shading and spawn inside the visiting kernels, no shading launch
 };
 
 void launch_init_frame(const LaunchCtx &c);
@@ -37,8 +38,10 @@ struct SortWorkspace {
     uint32_t tiles;     // capacity in tiles of RT_SORT_TILE pairs
 };
 // Sorts the first *n_dev of `count` pairs of `in` into `out`; pairs beyond are copied through.
+// plain_order: equal keys keep the order they have in `in`; otherwise the order of the reference's sort
+// (every tile of RT_SORT_TILE pairs read thread-major, sort.cl:26-27).
 void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pair *in, rt_index_pair *out,
-                 uint32_t count, const uint32_t *n_dev, uint32_t group_count);
+                 uint32_t count, const uint32_t *n_dev, uint32_t group_count, bool plain_order = false);
 uint32_t sort_key_bits(uint32_t group_count);
 // Looks up the workspace of rt_sort_pairs_static on the current device (once per device; allocates nothing).
 hipError_t sort_static_setup(void **out);

@@ -218,7 +218,7 @@ __global__ void k_copy_pairs(const rt_index_pair *src, rt_index_pair *dst, uint3
 }
 
 void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pair *in, rt_index_pair *out, uint32_t count,
-                 const uint32_t *n_dev, uint32_t group_count)
+                 const uint32_t *n_dev, uint32_t group_count, bool plain_order)
 {
     const uint32_t bits = sort_key_bits(group_count);
     const uint32_t passes = (bits + kRadixBits - 1) / kRadixBits;
@@ -237,7 +237,7 @@ void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pai
         k_sort_count<<<tiles, kSortThreads, 0, stream>>>(src, n_dev, ws.counts, ws.tiles, shift, mask);
         k_sort_scan<<<kRadix, 256, 0, stream>>>(ws.counts, ws.totals, n_dev, ws.tiles);
         k_sort_scatter<<<tiles, kSortThreads, 0, stream>>>(src, dst, final_pass ? in : nullptr, n_dev, ws.counts, ws.totals,
-                                                           ws.tiles, shift, mask, k == 0 ? 1u : 0u);
+                                                           ws.tiles, shift, mask, k == 0 && !plain_order ? 1u : 0u);
         src = dst;
     }
 }

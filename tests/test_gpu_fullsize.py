@@ -48,6 +48,16 @@ def test_full_model_finished_frame_matches_oracle(standin_full_ply):
     assert np.isfinite(rt.hits()["t"]).mean() > 0.2
     assert np.allclose(rt.area(), o.area, rtol=1e-5, atol=1e-6)
     assert np.abs(rt.draw_frame().astype(int) - o.resolve_rgba8().astype(int)).max() <= 1
+    rt.close()
+    # the free schedule (what the benchmark runs) gives every sample the same result
+    rt = api.RayTracer(sc, warp_width=64, sample_limit=limit, hit_capacity=limit, free_schedule=True)
+    run_to_completion(rt, steps_parked=10)
+    assert H.same_bytes(rt.hits(), o.hits)
+    assert np.allclose(rt.area(), o.area, rtol=1e-5, atol=1e-6)
+    assert np.abs(rt.draw_frame().astype(int) - o.resolve_rgba8().astype(int)).max() <= 1
+    c, oc = rt.counters(), o.counters()
+    for k in ("primary_spawned", "shadow_spawned"):
+        assert int(c[k]) == int(oc[k]), k
     rt.close(); o.close()
 
 
@@ -100,10 +110,13 @@ def test_headline_config_full_model(standin_full_ply):
     from oracle import pyoracle as O
     sc = S.build_scene([S.BUNNY, standin_full_ply], 1920, 1080, 1920 * 1080)
     assert sc.group_count == 9728
-    rt = api.RayTracer(sc, warp_width=64)
-    rt.init_frame()
-    assert rt.pool == 2080768
-    check_step_invariants(rt, rt.pool, 64)
+    for free in (True, False):
+        rt = api.RayTracer(sc, warp_width=64, free_schedule=free)
+        rt.init_frame()
+        assert rt.pool == 2080768
+        check_step_invariants(rt, rt.pool, 64)
+        if free:
+            rt.close()
     area = rt.area()
     assert np.isfinite(area).all() and area[:, 3].max() > 0
     rays = camera_rays(sc, 60000, np.random.default_rng(1080))

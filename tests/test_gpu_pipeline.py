@@ -157,6 +157,48 @@ def test_wave64_schedule_gives_the_same_samples(bunny_scene_64):
         rt.close()
 
 
+@pytest.mark.parametrize("warp,parked", [(64, 12), (32, 24), (1, 2)])
+def test_free_schedule_gives_the_same_samples(bunny_scene_64, warp, parked):
+    """RT_FLAG_FREE_SCHEDULE (plain-order sort, shading and spawn inside the visiting kernels) changes
+    which slot holds which sample at a given step, never a sample: hit records exact, colour sums and
+    image as for any other schedule."""
+    g = np.load(os.path.join(GOLDEN, "drain_bunny64.npz"))
+    limit = int(g["sample_limit"])
+    rt = api.RayTracer(bunny_scene_64, warp_width=warp, sample_limit=limit, hit_capacity=limit, free_schedule=True)
+    run_to_completion(rt, steps_parked=parked)
+    assert H.same_bytes(rt.hits(), g["hits"])
+    assert np.allclose(rt.area(), g["area"], rtol=1e-5, atol=1e-6)
+    assert np.abs(rt.draw_frame().astype(int) - g["image"].astype(int)).max() <= 1
+    c = rt.counters()
+    gc = g["counters"][0]
+    assert int(c["primary_spawned"]) == limit and int(c["shadow_spawned"]) == int(gc["shadow_spawned"])
+    rt.close()
+
+
+def test_free_schedule_keeps_the_step_invariants(bunny_scene_128):
+    """Sorted by group, whole waves per group, every slot exactly once, no shader key left in the index."""
+    rt = api.RayTracer(bunny_scene_128, warp_width=64, free_schedule=True)
+    rt.init_frame()
+    pool, prev = rt.pool, rt.pool
+    for chunk in range(6):
+        rt.make_step(8)
+        g = rt.global_data()[0]
+        n = int(g["ray_count"])
+        rays, index, groups = rt.dump_state()
+        ids = index["key"][:n] & L.GROUP_ID_MASK
+        assert n % 64 == 0 and np.all(np.diff(ids.astype(np.int64)) >= 0)
+        assert np.all(ids.reshape(-1, 64).min(axis=1) == ids.reshape(-1, 64).max(axis=1))
+        assert np.array_equal(np.sort(index["slot"]), np.arange(pool, dtype=np.uint32))
+        shader = index["key"][:n] >> 28
+        assert np.all((shader == L.SH_AABB) | (shader == L.SH_MESH) | (index["key"][:n] == 0))
+        assert np.array_equal(rays["queue"]["group_id"][index["slot"][:n], 0], index["key"][:n])
+        assert int(g["pixel_offset"]) >= prev
+        prev = int(g["pixel_offset"])
+    c = rt.counters()
+    assert int(c["primary_spawned"]) == prev
+    rt.close()
+
+
 def test_trace_closest_matches_oracle_and_brute_force(bunny_scene_64):
     from oracle import pyoracle as O
     from test_oracle_pipeline import camera_rays
@@ -178,6 +220,9 @@ def test_trace_closest_matches_oracle_and_brute_force(bunny_scene_64):
     o = O.Oracle(sc, warp_width=32)
     want = o.trace_closest(rays)
     assert H.same_bytes(got, want)            # t, leaf, instance, triangle: all bit-exact
+    free = api.RayTracer(sc, warp_width=64, free_schedule=True)
+    assert H.same_bytes(free.trace_closest(rays), want)
+    free.close()
     sub = np.arange(0, len(rays), 25)
     brute = H.brute_force_closest(sc, rays[sub])
     hit = np.isfinite(brute)
