@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -42,6 +43,7 @@ struct rt_ctx {
     rt_group *grp = nullptr;
     rt_matrix *mat = nullptr;
     rt_aabb *aabb = nullptr;
+    ClusterRecord *cluster = nullptr;
     rt_vertex *vtx = nullptr;
     uint32_t *tri = nullptr;
     TriRecord *tri_rec = nullptr;
@@ -100,7 +102,7 @@ LaunchCtx launch_ctx(const rt_ctx *c)
 {
     LaunchCtx l{};
     l.stream = c->stream;
-    l.scene = Scene{c->grp, c->mat, c->aabb, c->vtx, c->tri, c->tri_rec};
+    l.scene = Scene{c->grp, c->mat, c->aabb, c->cluster, c->vtx, c->tri, c->tri_rec};
     l.frame = Frame{c->glob, c->counters, c->area, c->rays, c->index, c->next, c->hits};
     l.cam = c->cam;
     l.grp_data = c->grp_data;
@@ -148,6 +150,7 @@ void free_scene(rt_ctx *c)
     dev_free(c->grp);
     dev_free(c->mat);
     dev_free(c->aabb);
+    dev_free(c->cluster);
     dev_free(c->vtx);
     dev_free(c->tri);
     dev_free(c->tri_rec);
@@ -175,6 +178,97 @@ void expand_leaf(const rt_mesh_shader &mesh, const rt_vertex *vtx, const uint32_
         r.n[1] = r.p[2] * r.q[0] - r.p[0] * r.q[2];
         r.n[2] = r.p[0] * r.q[1] - r.p[1] * r.q[0];
     }
+}
+
+// Wave-level culling data of one box list (see visit_aabb): the boxes are grouped into clusters of at
+// most eight, each with bounds that enclose its boxes strictly (one float step outwards on every
+// side, so that a ray parallel to a face of a box still meets the cluster's open slab).  A wave tests
+// the cluster bounds first and scans only the boxes of clusters some lane enters; a lane that misses
+// a cluster misses every box inside it (the slab test is monotonic in the bounds, rounding included),
+// so the accepted boxes, their order and their entry parameters are exactly those of a full scan.
+// Clusters are runs of eight consecutive boxes when the list is spatially ordered (the lists the
+// hierarchy builder emits are), otherwise median-split groups with a 256-bit membership mask each.
+struct ClusterSet {
+    std::vector<ClusterRecord> bounds, masks;  // masks empty: cluster c holds boxes [8c, 8c + 8)
+};
+
+ClusterRecord cluster_bounds(const rt_aabb *boxes, const std::vector<uint32_t> &members)
+{
+    ClusterRecord r;
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {1e30f, 1e30f, 1e30f};  // empty: no ray enters
+    bool any = false;
+    for (uint32_t i : members) {
+        const rt_aabb &b = boxes[i];
+        for (int k = 0; k < 3; k++) {
+            lo[k] = any ? std::min(lo[k], b.min[k]) : b.min[k];
+            hi[k] = any ? std::max(hi[k], b.max[k]) : b.max[k];
+        }
+        any = true;
+    }
+    for (int k = 0; k < 3; k++) {
+        r.f[k] = any ? std::nextafterf(lo[k], -INFINITY) : lo[k];
+        r.f[4 + k] = any ? std::nextafterf(hi[k], INFINITY) : hi[k];
+    }
+    r.f[3] = r.f[7] = 0;
+    return r;
+}
+
+double surface(const ClusterRecord &r)
+{
+    const double x = double(r.f[4]) - r.f[0], y = double(r.f[5]) - r.f[1], z = double(r.f[6]) - r.f[2];
+    return x * y + y * z + z * x;
+}
+
+void split_spatially(const rt_aabb *boxes, std::vector<uint32_t> ids, std::vector<std::vector<uint32_t>> &out)
+{
+    if (ids.size() <= 8) {
+        std::sort(ids.begin(), ids.end());
+        out.push_back(std::move(ids));
+        return;
+    }
+    float lo[3], hi[3];
+    auto centre = [&](uint32_t i, int k) { return 0.5f * (boxes[i].min[k] + boxes[i].max[k]); };
+    for (int k = 0; k < 3; k++) {
+        lo[k] = hi[k] = centre(ids[0], k);
+        for (uint32_t i : ids) {
+            lo[k] = std::min(lo[k], centre(i, k));
+            hi[k] = std::max(hi[k], centre(i, k));
+        }
+    }
+    int axis = 0;
+    for (int k = 1; k < 3; k++)
+        if (hi[k] - lo[k] > hi[axis] - lo[axis]) axis = k;
+    std::stable_sort(ids.begin(), ids.end(), [&](uint32_t x, uint32_t y) { return centre(x, axis) < centre(y, axis); });
+    const size_t half = (ids.size() + 1) / 2;
+    split_spatially(boxes, std::vector<uint32_t>(ids.begin(), ids.begin() + half), out);
+    split_spatially(boxes, std::vector<uint32_t>(ids.begin() + half, ids.end()), out);
+}
+
+ClusterSet build_clusters(const rt_aabb *boxes, uint32_t count)
+{
+    ClusterSet runs, spatial;
+    double cost_runs = 0, cost_spatial = 0;
+    for (uint32_t first = 0; first < count; first += 8) {
+        std::vector<uint32_t> members;
+        for (uint32_t i = first; i < count && i < first + 8; i++) members.push_back(i);
+        runs.bounds.push_back(cluster_bounds(boxes, members));
+        cost_runs += surface(runs.bounds.back());
+    }
+    if (count <= 16) return runs;
+    std::vector<uint32_t> all(count);
+    for (uint32_t i = 0; i < count; i++) all[i] = i;
+    std::vector<std::vector<uint32_t>> groups;
+    split_spatially(boxes, all, groups);
+    for (const std::vector<uint32_t> &members : groups) {
+        spatial.bounds.push_back(cluster_bounds(boxes, members));
+        cost_spatial += surface(spatial.bounds.back());
+        ClusterRecord mask;
+        std::memset(&mask, 0, sizeof(mask));
+        for (uint32_t i : members) mask.u[i / 32] |= 1u << (i % 32);
+        spatial.masks.push_back(mask);
+    }
+    // membership masks cost a load per box in the scan: only for lists that are far from spatial order
+    return cost_spatial < 0.5 * cost_runs && spatial.bounds.size() <= 32 ? spatial : runs;
 }
 
 hipError_t set_global_field(rt_ctx *c, size_t offset, const void *src, size_t size)
@@ -405,12 +499,15 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     int rc = visit(data->cam.root_group, "camera root");
     if (rc) return rc;
     // Device copies of the lists the kernels scan, re-laid out: every box list starts on a multiple of
-    // four boxes and is filled up to one with boxes no ray can enter, every leaf's triangles start on a
+    // eight boxes and is filled up to one with boxes no ray can enter, every leaf's triangles start on a
     // multiple of two and are filled up with null triangles no ray can hit, and both arrays end with
     // spare entries.  The scan loops then need no tail handling and may read ahead past a list's end.
     // The device group table carries the re-laid-out offsets.
     std::vector<rt_group> dev_grp(grp, grp + n_groups);
     std::vector<rt_aabb> dev_boxes;
+    std::vector<ClusterRecord> dev_clusters;
+    ClusterRecord no_cluster;
+    for (int k = 0; k < 8; k++) no_cluster.f[k] = k % 4 == 3 ? 0.0f : 1e30f;
     std::vector<uint32_t> dev_tri;
     std::vector<TriRecord> dev_rec;
     rt_aabb never;
@@ -434,9 +531,19 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
                 if ((s.flags & RT_F_LOCAL0) && b.local_id >= n_mat)
                     return fail(c, RT_ERR_INVALID_VALUE, "box %u: instance %u of %zu matrices", s.aabb_offs + i, b.local_id, n_mat);
             }
-            dev_grp[id & RT_GROUP_ID_MASK].aabb.aabb_offs = uint32_t(dev_boxes.size());
+            uint32_t *entry = reinterpret_cast<uint32_t *>(&dev_grp[id & RT_GROUP_ID_MASK]);
+            entry[0] = uint32_t(dev_boxes.size());
             dev_boxes.insert(dev_boxes.end(), aabb + s.aabb_offs, aabb + s.aabb_offs + s.aabb_count);
-            while (dev_boxes.size() % 4) dev_boxes.push_back(never);
+            while (dev_boxes.size() % 8) dev_boxes.push_back(never);
+            // clusters of the list: [bounds, filled up to a multiple of four][membership masks, if any]
+            const ClusterSet set = build_clusters(aabb + s.aabb_offs, s.aabb_count);
+            const uint32_t clusters = uint32_t(set.bounds.size());
+            entry[2] = (s.flags & 0xFFu) | clusters << kClusterCountShift | (set.masks.empty() ? 0u : kClusterMasked);
+            entry[3] = uint32_t(dev_clusters.size());
+            dev_clusters.insert(dev_clusters.end(), set.bounds.begin(), set.bounds.end());
+            while (dev_clusters.size() % 4) dev_clusters.push_back(no_cluster);
+            dev_clusters.insert(dev_clusters.end(), set.masks.begin(), set.masks.end());
+            while (dev_clusters.size() % 4) dev_clusters.push_back(no_cluster);
         } else {
             const rt_mesh_shader &s = g.mesh;
             if (uint64_t(s.tri_offs) + s.tri_count > n_tri)
@@ -461,6 +568,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
         }
     }
     dev_boxes.insert(dev_boxes.end(), 8, never);
+    dev_clusters.insert(dev_clusters.end(), 8, no_cluster);
     dev_tri.insert(dev_tri.end(), 6, 0u);
     dev_rec.insert(dev_rec.end(), 6, null_tri);
     if (dev_boxes.size() > 0x7FFFFFFFu || dev_tri.size() > 0x7FFFFFFFu) return fail(c, RT_ERR_UNSUPPORTED, "scene too large");
@@ -475,6 +583,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     RT_HIP(c, dev_alloc(c->grp, G));
     RT_HIP(c, dev_alloc(c->mat, n_mat));
     RT_HIP(c, dev_alloc(c->aabb, dev_boxes.size()));
+    RT_HIP(c, dev_alloc(c->cluster, dev_clusters.size()));
     RT_HIP(c, dev_alloc(c->vtx, n_vtx));
     RT_HIP(c, dev_alloc(c->tri, dev_tri.size()));
     RT_HIP(c, dev_alloc(c->tri_rec, dev_rec.size()));
@@ -485,6 +594,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     RT_HIP(c, hipMemcpy(c->grp, dev_grp.data(), sizeof(rt_group) * n_groups, hipMemcpyHostToDevice));
     if (n_mat) RT_HIP(c, hipMemcpy(c->mat, mat, sizeof(rt_matrix) * n_mat, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->aabb, dev_boxes.data(), sizeof(rt_aabb) * dev_boxes.size(), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->cluster, dev_clusters.data(), sizeof(ClusterRecord) * dev_clusters.size(), hipMemcpyHostToDevice));
     if (n_vtx) RT_HIP(c, hipMemcpy(c->vtx, vtx, sizeof(rt_vertex) * n_vtx, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->tri, dev_tri.data(), sizeof(uint32_t) * dev_tri.size(), hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->tri_rec, dev_rec.data(), sizeof(TriRecord) * dev_rec.size(), hipMemcpyHostToDevice));

@@ -71,10 +71,20 @@ struct CompactWorkspace {
     uint32_t *ticket;    // blocks finished; zero between launches
 };
 
+// One 32-byte record of the culling data of a box list: the bounds of a cluster of boxes
+// (min.xyz, -, max.xyz, -) or the 256-bit membership mask of a cluster.
+union alignas(32) ClusterRecord {
+    float f[8];
+    uint32_t u[8];
+};
+// Device copy of a box group's entry: {first box, boxes, flags | clusters << 8 | masked << 16, first cluster record}.
+constexpr uint32_t kClusterCountShift = 8, kClusterCountMask = 0xFF, kClusterMasked = 1u << 16;
+
 struct Scene {
     const rt_group *grp;
     const rt_matrix *mat;
     const rt_aabb *aabb;
+    const ClusterRecord *cluster;
     const rt_vertex *vtx;
     const uint32_t *tri;
     const TriRecord *tri_rec;
@@ -85,7 +95,12 @@ struct Scene {
 // which is as long as a whole kernel here, and every wave would sit out its own atomic at its next
 // wait for a load (vmcnt counts atomics too).
 constexpr uint32_t kCounterShards = 1024;
-enum Counter : uint32_t { kPrimarySpawned = 0, kShadowSpawned = 1, kBoxTests = 2, kTriTests = 3, kCounterKinds = 8 };
+enum Counter : uint32_t {
+    kPrimarySpawned = 0, kShadowSpawned = 1,
+    kBoxTests = 2, kTriTests = 3,  // what the reference's loops would test (every box / triangle of a visited group, per ray)
+    kBoxScanned = 4,               // cluster and box tests actually executed per ray (builds with RT_COUNT_SCANNED only; shares its place with the phase stamps of diagnostic builds)
+    kCounterKinds = 8
+};
 
 struct Frame {
     DevGlobal *glob;
@@ -144,6 +159,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 

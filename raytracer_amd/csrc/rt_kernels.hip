@@ -599,18 +599,43 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         n = wave_visit_one(a.scene.aabb + grp.x, count, lr.start, inv_dir, lr.tmin, lr.tmax, c_pos, c_idx);
         if (lane_id() != owner) return true;
     } else {
-    // Box scan.  The list is wave-uniform and comes through the scalar cache, 64 bytes (two boxes) per
-    // load; the device copy of a list starts on a 128-byte boundary, is filled up to a multiple of
-    // four with boxes no ray can enter and is followed by readable entries, so four boxes are tested
-    // per half iteration without tail handling, while the loads for the next four are in flight.
-    ConstPtr<f32x16> pair = const_ptr<f32x16>(a.scene.aabb + grp.x);  // per box: min.xyz, group id, max.xyz, local id
+    // Box scan.  The list is wave-uniform and comes through the scalar cache.  First the bounds of the
+    // list's clusters (up to eight boxes each) are tested: a cluster no lane of the wave enters is
+    // skipped, which cannot change any lane's result (see build_clusters in rt_api.hip).  Then the
+    // boxes of the entered clusters are tested in list order, so every lane collects its candidates
+    // in the order the reference's loop does (shader.cl:84-99).  The device copies of both lists are
+    // filled up with entries no ray can enter and followed by readable spare entries: the loops have
+    // no tail handling and always have the next 128 bytes in flight while the current ones are tested.
     asm volatile("" ::"v"(inv_dir.x), "v"(inv_dir.y), "v"(inv_dir.z), "v"(lr.start.x));
     AABB_STAMP(t_loaded);
     bool spill = false;
-    auto test_pair = [&](const f32x16 p, uint32_t i) {
+    uint32_t entered = 0;
+    const uint32_t clusters = (grp.z >> kClusterCountShift) & kClusterCountMask;
+    if (clusters) {
+        ConstPtr<f32x16> two = const_ptr<f32x16>(a.scene.cluster + grp.w);  // bounds of two clusters per load
+        auto test_two = [&](const f32x16 p, uint32_t c) {
+            float t;
+            if (__ballot(box_test(p.lo, lr.start, inv_dir, lr.tmin, lr.tmax, t))) entered |= 1u << c;
+            if (__ballot(box_test(p.hi, lr.start, inv_dir, lr.tmin, lr.tmax, t))) entered |= 2u << c;
+        };
+        f32x16 c0 = two[0];
+        for (uint32_t c = 0;; c += 4) {
+            scalar_loads_landed();
+            const f32x16 c1 = two[c / 2 + 1];
+            test_two(c0, c);
+            if (c + 2 >= clusters) break;
+            scalar_loads_landed();
+            c0 = two[c / 2 + 2];
+            test_two(c1, c + 2);
+            if (c + 4 >= clusters) break;
+        }
+    }
+#ifdef RT_COUNT_SCANNED
+    uint32_t scanned = clusters;
+#endif
+    auto test_box = [&](const f32x8 b, uint32_t i) {
         float t;
-        const bool hit0 = box_test(p.lo, lr.start, inv_dir, lr.tmin, lr.tmax, t);
-        if (hit0) {
+        if (box_test(b, lr.start, inv_dir, lr.tmin, lr.tmax, t)) {
             if (n < CAP) {
                 s_pos[n][tid] = t;
                 s_idx[n][tid] = (uint8_t)i;
@@ -619,33 +644,88 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
                 spill = true;
             }
         }
-        const bool hit1 = box_test(p.hi, lr.start, inv_dir, lr.tmin, lr.tmax, t);
-        if (hit1) {
-            if (n < CAP) {
-                s_pos[n][tid] = t;
-                s_idx[n][tid] = (uint8_t)(i + 1);
-                n++;
-            } else {
-                spill = true;
+    };
+    if (!(grp.z & kClusterMasked)) {
+        // cluster c = boxes [8c, 8c + 8): two loads of 128 bytes per half cluster, ping-pong
+        ConstPtr<f32x16> pair = const_ptr<f32x16>(a.scene.aabb + grp.x);  // per box: min.xyz, group id, max.xyz, local id
+        if (entered) {
+            uint32_t c = (uint32_t)__builtin_ctz(entered);
+            entered &= entered - 1;
+            f32x16 a0 = pair[4 * c], a1 = pair[4 * c + 1];
+            for (;;) {
+                scalar_loads_landed();  // a0, a1 are in; only then ask for the next four boxes
+                const f32x16 b0 = pair[4 * c + 2], b1 = pair[4 * c + 3];
+                test_box(a0.lo, 8 * c);
+                test_box(a0.hi, 8 * c + 1);
+                test_box(a1.lo, 8 * c + 2);
+                test_box(a1.hi, 8 * c + 3);
+                const bool more = entered != 0;
+                const uint32_t next = more ? (uint32_t)__builtin_ctz(entered) : c;  // (a harmless reload at the end)
+                entered &= entered - 1;
+                scalar_loads_landed();
+                a0 = pair[4 * next];
+                a1 = pair[4 * next + 1];
+                test_box(b0.lo, 8 * c + 4);
+                test_box(b0.hi, 8 * c + 5);
+                test_box(b1.lo, 8 * c + 6);
+                test_box(b1.hi, 8 * c + 7);
+#ifdef RT_COUNT_SCANNED
+                scanned += 8;
+#endif
+                if (!more) break;
+                c = next;
             }
         }
-    };
-    if (count) {
-        f32x16 a0 = pair[0], a1 = pair[1];
-        for (uint32_t i = 0;; i += 8) {
-            scalar_loads_landed();  // a0, a1 are in; only then ask for the next four
-            const f32x16 b0 = pair[i / 2 + 2], b1 = pair[i / 2 + 3];
-            test_pair(a0, i);
-            test_pair(a1, i + 2);
-            if (i + 4 >= count) break;
+    } else {
+        // clusters with membership masks: the boxes of the entered clusters, in list order
+        ConstPtr<u64x4> masks = const_ptr<u64x4>(a.scene.cluster + grp.w + ((clusters + 3) & ~3u));
+        unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        while (entered) {
+            const uint32_t c = (uint32_t)__builtin_ctz(entered);
+            entered &= entered - 1;
+            const uint32_t c2 = entered ? (uint32_t)__builtin_ctz(entered) : c;
+            entered &= entered - 1;
+            const u64x4 x = masks[c], y = masks[c2];
             scalar_loads_landed();
-            a0 = pair[i / 2 + 4];
-            a1 = pair[i / 2 + 5];
-            test_pair(b0, i + 4);
-            test_pair(b1, i + 6);
-            if (i + 8 >= count) break;
+            m0 |= x.x | y.x;
+            m1 |= x.y | y.y;
+            m2 |= x.z | y.z;
+            m3 |= x.w | y.w;
         }
+        ConstPtr<f32x8> box = const_ptr<f32x8>(a.scene.aabb + grp.x);
+        auto scan_word = [&](unsigned long long m, uint32_t first) {
+            while (m) {
+                // up to four boxes per round: their loads are in flight together
+                uint32_t i0 = first + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const bool h1 = m != 0;
+                const uint32_t i1 = h1 ? first + (uint32_t)__builtin_ctzll(m) : i0;
+                m &= m - 1;
+                const bool h2 = m != 0;
+                const uint32_t i2 = h2 ? first + (uint32_t)__builtin_ctzll(m) : i0;
+                m &= m - 1;
+                const bool h3 = m != 0;
+                const uint32_t i3 = h3 ? first + (uint32_t)__builtin_ctzll(m) : i0;
+                m &= m - 1;
+                const f32x8 b0 = box[i0], b1 = box[i1], b2 = box[i2], b3 = box[i3];
+                scalar_loads_landed();
+                test_box(b0, i0);
+                if (h1) test_box(b1, i1);
+                if (h2) test_box(b2, i2);
+                if (h3) test_box(b3, i3);
+#ifdef RT_COUNT_SCANNED
+                scanned += 1 + h1 + h2 + h3;
+#endif
+            }
+        };
+        scan_word(m0, 0);
+        scan_word(m1, 64);
+        scan_word(m2, 128);
+        scan_word(m3, 192);
     }
+#ifdef RT_COUNT_SCANNED
+    count_lanes(a.frame, kBoxScanned, true, scanned);
+#endif
     AABB_STAMP(t_scanned);
     AABB_STAMP_ADD(a.frame, 0, t_start, t_loaded);
     AABB_STAMP_ADD(a.frame, 1, t_loaded, t_scanned);
@@ -664,6 +744,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 
     // sort_hits (ray-tracer.cl:90-117): the reference's compare-exchange network, run with
     // wave-uniform (i, j) so every LDS access has a uniform row; lanes with fewer entries idle.
+    AABB_STAMP(t_queue);
     if (!COOP) {
     const uint32_t n_max = wave_max_upto127(n);
     auto exchange = [&](uint32_t j, uint32_t i) {
@@ -686,7 +767,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     }
 
     AABB_STAMP(t_sorted);
-    AABB_STAMP_ADD(a.frame, 2, t_scanned, t_sorted);
+    AABB_STAMP_ADD(a.frame, 2, t_queue, t_sorted);
     // insert_hits (ray-tracer.cl:205-231): merge the sorted candidates with the pending entries, old
     // entry first on equal position, at most 8 entries, the 8th turned into a root restart.  Both
     // lists are sorted, so every entry's place in the merged queue is a count: a pending entry i goes

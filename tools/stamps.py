@@ -8,7 +8,9 @@ dragon = os.path.join(tempfile.gettempdir(), "rt_dragon_standin_tool.ply")
 if not os.path.exists(dragon):
     S.write_standin_ply(dragon)
 sc = S.build_scene([S.BUNNY, dragon], 1920, 1080, 1920 * 1080)
-rt = api.RayTracer(sc, warp_width=64)
+FREE = os.environ.get("RT_SCHEDULE", "free") == "free"
+rt = api.RayTracer(sc, warp_width=64, free_schedule=FREE)
+print("schedule:", "free" if FREE else "reference")
 rt.init_frame(); rt.make_step(96); rt.sync()
 rt.debug_stamps(reset=True)
 rt.make_step(32); rt.sync()
