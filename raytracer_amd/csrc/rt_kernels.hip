@@ -579,11 +579,12 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
 template <int CAP, int THREADS, bool COOP>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
                                            uint8_t (*s_idx)[THREADS], float *c_pos, uint8_t *c_idx, uint32_t owner,
-                                           uint32_t tid, uint32_t &new_key)
+                                           uint32_t tid, uint32_t &new_key, uint32_t &group_flags)
 {
     AABB_STAMP(t_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
     const uint32_t count = grp.y;
+    group_flags = grp.z;
     // What the scan needs from the slot (meta, ray, head of the queue: its first 64 bytes) is requested
     // now.  No load is issued once the stores of the merge begin.
     const uint4 meta = *reinterpret_cast<const uint4 *>(ray);  // pixel, type, material_id, queue_len
@@ -894,12 +895,23 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
     }
 
     uint32_t new_key = key;
-    bool done = true, todo = true;
-    while (todo) {
-        if (key != __builtin_amdgcn_readfirstlane(key)) continue;
-        todo = false;
-        const uint32_t g = uniform_value(key);  // every lane still here holds the same key
-        done = visit_aabb<kAabbCap, kAabbThreads, false>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key);
+    bool done = true;
+    for (int round = 0;; round++) {
+        uint32_t group_flags = 0;
+        bool todo = true;
+        while (todo) {
+            if (key != __builtin_amdgcn_readfirstlane(key)) continue;
+            todo = false;
+            const uint32_t g = uniform_value(key);  // every lane still here holds the same key
+            done = visit_aabb<kAabbCap, kAabbThreads, false>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key, group_flags);
+        }
+        // Free schedule: a ray that has just been through a list of instances (the scene root) and whose
+        // nearest node is a model's root goes through that root now.  A wave's rays enter few distinct
+        // models, so the second visit is nearly as coherent as the first, and the ray saves a whole step.
+        if (!FREE || round || !done || !(group_flags & RT_F_LOCAL0)) break;
+        if (((new_key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) != RT_SH_AABB) break;
+        asm volatile("" ::: "memory");  // the next visit reads what this one has stored to the slot
+        key = new_key;
     }
     // Rare (3 visits in 10,000 on the benchmark scene): lanes whose columns overflowed and whose rays are
     // therefore untouched.  Their positions go to a list (one atomic per wave); k_process_aabb_big
@@ -945,8 +957,9 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
         // the group the ray is in: the key of its index entry, except for a sample the box kernel has just started
         const uint32_t g = uniform_value(ray->queue[0].group_id);
         uint32_t new_key = g;
+        uint32_t group_flags;
         visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true>(g, ray, a, nullptr, nullptr, s_wave_pos[wave], s_wave_idx[wave], 0, tid,
-                                                        new_key);
+                                                        new_key, group_flags);
         if (lane_id() == 0) {
             if (FREE) new_key = run_end_group(new_key, ray, a);
             a.frame.next[index] = rt_index_pair{new_key, slot};
