@@ -199,7 +199,9 @@ int rt_get_counters(rt_ctx *ctx, rt_counters *dst);
  * sorts the first n of `count` pairs by the low key bits needed for group_count groups, reading the
  * input block-wise in thread-major order as local_count does (sort.cl:26-27), and copies pairs
  * [n, count) through.  in/out are host pointers, or device pointers when on_device != 0; they must
- * not overlap.  count must be a multiple of RT_SORT_TILE and at most the context's pool size. */
+ * not overlap.  count must be a multiple of RT_SORT_TILE and at most the context's pool size.
+ * On a context created with RT_FLAG_FREE_SCHEDULE the sort is the one that context's steps use: stable
+ * over the plain order of the first n pairs, by the bits of group_count - 1. */
 int rt_sort_pairs(rt_ctx *ctx, const rt_index_pair *in, rt_index_pair *out,
                   uint32_t count, uint32_t n, uint32_t group_count, int on_device);
 

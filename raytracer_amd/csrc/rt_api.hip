@@ -423,7 +423,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
     RT_HIP(c, dev_alloc(c->rgba, c->area_size));
     RT_HIP(c, dev_alloc(c->spill_list, c->pool));
     c->ws.tiles = c->pool / RT_SORT_TILE;
-    RT_HIP(c, dev_alloc(c->ws.counts, size_t(256) * c->ws.tiles));
+    RT_HIP(c, dev_alloc(c->ws.counts, size_t(256) * c->ws.tiles * kSortCountsPerTile));
     RT_HIP(c, dev_alloc(c->ws.totals, 256));
     RT_HIP(c, hipMemsetAsync(c->glob, 0, sizeof(DevGlobal), c->stream));
     RT_HIP(c, hipMemsetAsync(c->hits, 0, sizeof(rt_hit_record) * size_t(cfg->hit_capacity ? cfg->hit_capacity : 1), c->stream));
@@ -759,7 +759,8 @@ int rt_sort_pairs(rt_ctx *c, const rt_index_pair *in, rt_index_pair *out, uint32
         RT_HIP(c, hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, c->stream));
     }
     RT_HIP(c, set_global_field(c, offsetof(DevGlobal, sort_count), &n, sizeof(n)));
-    launch_sort(c->stream, c->ws, on_device ? in : d_in, on_device ? out : d_out, count, &c->glob->sort_count, group_count);
+    launch_sort(c->stream, c->ws, on_device ? in : d_in, on_device ? out : d_out, count, &c->glob->sort_count, group_count,
+                c->free_schedule);
     int rc = check_launch(c, "sort");
     if (!on_device && !rc) {
         const hipError_t err = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream);

@@ -31,8 +31,10 @@ void launch_resolve(const LaunchCtx &c, void *out_dev);
 void launch_export_rays(const LaunchCtx &c, rt_ray_queue *out_dev);
 
 // Radix sort of (key, slot) pairs, see rt_sort.hip.
+constexpr uint32_t kSortCountsPerTile = 4;  // plain-order sorts cut every tile of RT_SORT_TILE pairs into four
 struct SortWorkspace {
-    uint32_t *counts;   // [256][tiles] per-tile digit counts, scanned in place
+    uint32_t *counts;   // [256][tiles * kSortCountsPerTile] per-tile digit counts, scanned in place (the static
+                        // workspace of rt_sort_pairs_static, which only sorts in the reference's order, holds [256][tiles])
     uint32_t *totals;   // [256] per-digit totals of a pass
     rt_index_pair *tmp; // one pool-sized ping-pong buffer
     uint32_t tiles;     // capacity in tiles of RT_SORT_TILE pairs

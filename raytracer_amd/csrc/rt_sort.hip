@@ -16,12 +16,14 @@
 
 namespace rtd {
 
-constexpr uint32_t kTile = RT_SORT_TILE;
-constexpr uint32_t kSortThreads = 512;
-constexpr uint32_t kSortWaves = kSortThreads / 64;
-constexpr uint32_t kPerThread = kTile / kSortThreads;  // 16
+constexpr uint32_t kTile = RT_SORT_TILE;   // the reference's sort block: its thread-major order is defined on it
+constexpr uint32_t kSortThreads = 512;     // ... by 512 work-items owning 16 pairs each (sort.cl:26-27)
 constexpr uint32_t kRadixBits = 8;
 constexpr uint32_t kRadix = 1u << kRadixBits;
+// Plain-order sorts (free schedule) are free to use smaller tiles: four times as many workgroups, a
+// quarter of the LDS each, so that several are resident per CU and the passes stop being latency-bound.
+constexpr uint32_t kSmallTile = 2048, kSmallThreads = 256;
+static_assert(kTile == kSmallTile * kSortCountsPerTile, "pools are whole reference tiles, hence whole small tiles");
 
 // Key bits the reference's pass loop covers: 5 bits per pass while (group_count-1) >> 5p is non-zero,
 // at most the 24 id bits (main.cpp:444-445).
@@ -59,29 +61,36 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 }
 
 // Per-tile digit histogram of one pass: counts[digit * tiles + tile].
-__global__ __launch_bounds__(kSortThreads) void k_sort_count(const rt_index_pair *src, const uint32_t *n_ptr,
-                                                             uint32_t *counts, uint32_t tiles, uint32_t shift, uint32_t mask)
+template <uint32_t TILE, uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void k_sort_count(const rt_index_pair *src, const uint32_t *n_ptr,
+                                                        uint32_t *counts, uint32_t tiles, uint32_t shift, uint32_t mask)
 {
+    constexpr uint32_t kPerThread = TILE / THREADS;
     __shared__ uint32_t hist[kRadix];
-    const uint32_t tid = threadIdx.x, tile = blockIdx.x, base = tile * kTile, n = *n_ptr;
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, base = tile * TILE, n = *n_ptr;
     if (base >= n) return;
-    if (tid < kRadix) hist[tid] = 0;
+    for (uint32_t d = tid; d < kRadix; d += THREADS) hist[d] = 0;
     __syncthreads();
-#pragma unroll 4
-    for (uint32_t i = 0; i < kPerThread; i++) {
-        const uint32_t p = base + i * kSortThreads + tid;
-        if (p < n) atomicAdd(&hist[(src[p].key >> shift) & mask], 1u);
+    uint32_t keys[kPerThread];
+#pragma unroll
+    for (uint32_t i = 0; i < kPerThread; i++) {  // all loads first: they are in flight together
+        const uint32_t p = base + i * THREADS + tid;
+        keys[i] = p < n ? src[p].key : 0xFFFFFFFFu;
     }
+#pragma unroll
+    for (uint32_t i = 0; i < kPerThread; i++)
+        if (base + i * THREADS + tid < n) atomicAdd(&hist[(keys[i] >> shift) & mask], 1u);
     __syncthreads();
-    if (tid < kRadix) counts[tid * tiles + tile] = hist[tid];
+    for (uint32_t d = tid; d < kRadix; d += THREADS) counts[d * tiles + tile] = hist[d];
 }
 
 // One block per digit: exclusive scan of that digit's counts over the active tiles, and its total.
-__global__ __launch_bounds__(256) void k_sort_scan(uint32_t *counts, uint32_t *totals, const uint32_t *n_ptr, uint32_t tiles)
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t *counts, uint32_t *totals, const uint32_t *n_ptr, uint32_t tiles,
+                                                   uint32_t tile_size)
 {
     __shared__ uint32_t s_wave[4];
     const uint32_t tid = threadIdx.x, n = *n_ptr;
-    const uint32_t active = (n + kTile - 1) / kTile;
+    const uint32_t active = (n + tile_size - 1) / tile_size;
     uint32_t *row = counts + blockIdx.x * tiles;
     const uint32_t per = (active + 255) / 256;
     const uint32_t first = tid * per < active ? tid * per : active;
@@ -100,12 +109,14 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *counts, uint32_t *t
 
 // Scatter of one pass.  first_pass: read the tile in the reference's thread-major order.
 // tail_src (final pass only): where pairs at or beyond n are copied from.
-__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const rt_index_pair *src, rt_index_pair *dst,
-                                                               const rt_index_pair *tail_src, const uint32_t *n_ptr,
-                                                               const uint32_t *counts, const uint32_t *totals,
-                                                               uint32_t tiles, uint32_t shift, uint32_t mask,
-                                                               uint32_t first_pass)
+template <uint32_t TILE, uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void k_sort_scatter(const rt_index_pair *src, rt_index_pair *dst,
+                                                          const rt_index_pair *tail_src, const uint32_t *n_ptr,
+                                                          const uint32_t *counts, const uint32_t *totals,
+                                                          uint32_t tiles, uint32_t shift, uint32_t mask,
+                                                          uint32_t first_pass)
 {
+    constexpr uint32_t kTile = TILE, kSortThreads = THREADS, kSortWaves = THREADS / 64, kPerThread = TILE / THREADS;
     // The tile, one padding slot after every 16 pairs: the transposing store (stride 16 pairs per
     // thread) and the linear 8-byte reads are then both free of bank conflicts.
     __shared__ uint2 s_tile[kTile + kTile / 16];
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const rt_index_pa
     }
     uint32_t unused;
     const uint32_t start = block_exclusive_scan<kSortThreads>(digit_count, s_wave, unused);
-    const uint32_t digit_base = block_exclusive_scan<kSortThreads>(tid < kRadix ? totals[tid] : 0u, s_wave, unused);
+    const uint32_t digit_base = block_exclusive_scan<kSortThreads>(tid <= mask ? totals[tid] : 0u, s_wave, unused);
     if (tid < kRadix) {
         s_start[tid] = start;
         s_gbase[tid] = digit_base + counts[tid * tiles + tile] - start;
@@ -217,29 +228,42 @@ __global__ void k_copy_pairs(const rt_index_pair *src, rt_index_pair *dst, uint3
     if (i < count) dst[i] = src[i];
 }
 
+template <uint32_t TILE, uint32_t THREADS>
+static void sort_passes(hipStream_t stream, const SortWorkspace &ws, const rt_index_pair *in, rt_index_pair *out, uint32_t count,
+                        const uint32_t *n_dev, uint32_t bits, uint32_t passes, bool thread_major)
+{
+    const uint32_t tiles = count / TILE, stride = ws.tiles * (kTile / TILE);  // counts rows are sized for the context's pool
+    const uint32_t digit_bits = (bits + passes - 1) / passes;
+    const rt_index_pair *src = in;
+    for (uint32_t k = 0; k < passes; k++) {
+        const uint32_t shift = k * digit_bits;
+        const uint32_t width = bits - shift < digit_bits ? bits - shift : digit_bits;
+        const uint32_t mask = (1u << width) - 1;
+        const bool final_pass = k + 1 == passes;
+        rt_index_pair *dst = ((passes - 1 - k) % 2 == 0) ? out : ws.tmp;
+        k_sort_count<TILE, THREADS><<<tiles, THREADS, 0, stream>>>(src, n_dev, ws.counts, stride, shift, mask);
+        k_sort_scan<<<mask + 1, 256, 0, stream>>>(ws.counts, ws.totals, n_dev, stride, TILE);
+        k_sort_scatter<TILE, THREADS><<<tiles, THREADS, 0, stream>>>(src, dst, final_pass ? in : nullptr, n_dev, ws.counts,
+                                                                     ws.totals, stride, shift, mask, k == 0 && thread_major ? 1u : 0u);
+        src = dst;
+    }
+}
+
 void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pair *in, rt_index_pair *out, uint32_t count,
                  const uint32_t *n_dev, uint32_t group_count, bool plain_order)
 {
-    const uint32_t bits = sort_key_bits(group_count);
+    // The reference's pass loop covers 5 key bits per pass (sort_key_bits); sorting by exactly those bits
+    // is part of its output.  In plain order only the grouping matters: the bits of group_count - 1.
+    uint32_t bits = sort_key_bits(group_count);
+    if (plain_order)
+        for (bits = 0; bits < 24 && ((group_count - 1) >> bits); bits++) {}
     const uint32_t passes = (bits + kRadixBits - 1) / kRadixBits;
     if (passes == 0) {
         k_copy_pairs<<<(count + 255) / 256, 256, 0, stream>>>(in, out, count);
         return;
     }
-    const uint32_t tiles = count / kTile;
-    const rt_index_pair *src = in;
-    for (uint32_t k = 0; k < passes; k++) {
-        const uint32_t shift = k * kRadixBits;
-        const uint32_t width = bits - shift < kRadixBits ? bits - shift : kRadixBits;
-        const uint32_t mask = (1u << width) - 1;
-        const bool final_pass = k + 1 == passes;
-        rt_index_pair *dst = ((passes - 1 - k) % 2 == 0) ? out : ws.tmp;
-        k_sort_count<<<tiles, kSortThreads, 0, stream>>>(src, n_dev, ws.counts, ws.tiles, shift, mask);
-        k_sort_scan<<<kRadix, 256, 0, stream>>>(ws.counts, ws.totals, n_dev, ws.tiles);
-        k_sort_scatter<<<tiles, kSortThreads, 0, stream>>>(src, dst, final_pass ? in : nullptr, n_dev, ws.counts, ws.totals,
-                                                           ws.tiles, shift, mask, k == 0 && !plain_order ? 1u : 0u);
-        src = dst;
-    }
+    if (plain_order) sort_passes<kSmallTile, kSmallThreads>(stream, ws, in, out, count, n_dev, bits, passes, false);
+    else sort_passes<kTile, kSortThreads>(stream, ws, in, out, count, n_dev, bits, passes, true);
 }
 
 }  // namespace rtd

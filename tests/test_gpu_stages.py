@@ -54,6 +54,22 @@ def test_sort_skewed_keys(ctx):
         assert H.same_bytes(ctx.sort_pairs(pairs, 32000, 9728), H.expected_sort(pairs, 32000, 9728))
 
 
+@pytest.mark.parametrize("group_count", [2, 512, 9728, 70144])
+def test_plain_order_sort_of_the_free_schedule(group_count):
+    """A context with RT_FLAG_FREE_SCHEDULE sorts with small tiles and keeps equal group ids in their
+    plain order: exactly numpy's stable sort by group id."""
+    sc = S.build_scene([S.BUNNY], 1920, 1080, 1920 * 1080, n_obj=4)
+    rt = api.RayTracer(sc, free_schedule=True)
+    rng = np.random.default_rng(group_count)
+    for count, n in ((8192, 8192), (8192, 1), (8192, 0), (16384, 8193), (32768, 32736), (rt.pool, rt.pool - 64 * 999 - 7)):
+        pairs = H.random_pairs(rng, count, group_count)
+        want = pairs.copy()
+        order = np.argsort(pairs["key"][:n] & L.GROUP_ID_MASK, kind="stable")
+        want[:n] = pairs[:n][order]
+        assert H.same_bytes(rt.sort_pairs(pairs, n, group_count), want), (count, n)
+    rt.close()
+
+
 def test_sort_rejects_bad_arguments(ctx):
     pairs = np.zeros(8192, L.index_pair_dtype)
     with pytest.raises(api.RtError, match="RT_ERR_INVALID_VALUE"):

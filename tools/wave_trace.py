@@ -9,7 +9,7 @@ dragon = os.path.join(tempfile.gettempdir(), "rt_dragon_standin_tool.ply")
 if not os.path.exists(dragon):
     S.write_standin_ply(dragon)
 sc = S.build_scene([S.BUNNY, dragon], 1920, 1080, 1920 * 1080)
-rt = api.RayTracer(sc, warp_width=64)
+rt = api.RayTracer(sc, warp_width=64, free_schedule=os.environ.get("RT_SCHEDULE", "free") == "free")
 rt.init_frame(); rt.make_step(120); rt.sync()
 ptr = rt.debug_stamps()[7]
 n = rt.pool // 64
