@@ -34,6 +34,7 @@ struct rt_ctx {
     uint32_t *spill_list = nullptr;
     rt_group_data *grp_data = nullptr;
     CompactWorkspace compact = {nullptr, nullptr, nullptr};
+    FusedWorkspace fused = {nullptr, nullptr};  // free schedule with at most kFusedMaxGroups groups: sort + compaction as one sequence
     uchar4 *rgba = nullptr;
     SortWorkspace ws{};
     hipGraphExec_t step_graph = nullptr;  // one step (both streams), captured on first use; dropped when its arguments change
@@ -156,6 +157,8 @@ void free_scene(rt_ctx *c)
     dev_free(c->tri_rec);
     dev_free(c->grp_data);
     free_compact(c->compact);
+    dev_free(c->fused.ghist);
+    dev_free(c->fused.block_main);
     c->scene_ready = c->frame_ready = false;
 }
 
@@ -285,7 +288,7 @@ int resolve_timers(rt_ctx *c)
         float ms = 0;
         RT_HIP(c, hipEventElapsedTime(&ms, span.from, span.to));
         c->stage_ms[span.stage] += ms;
-        if (span.stage == RT_STAGE_COMPACT) c->timed_steps++;
+        if (span.stage == RT_STAGE_SORT) c->timed_steps++;
         c->spare.push_back(span.from);
         c->spare.push_back(span.to);
     }
@@ -344,12 +347,23 @@ int one_step(rt_ctx *c, bool run_process)
         if (!c->free_schedule && (rc = timed(c, RT_STAGE_SHADE, c->stream, [&] { launch_process_shade(l); }))) return rc;
         if (fork) RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
-    rc = timed(c, RT_STAGE_SORT, c->stream, [&] {
-        launch_sort(c->stream, c->ws, run_process ? c->next : c->index, c->sorted, c->pool, &c->glob->g.ray_count, c->group_count,
-                    c->free_schedule);
-    });
-    if (rc) return rc;
-    if ((rc = timed(c, RT_STAGE_COMPACT, c->stream, [&] { launch_compact(l, c->sorted, c->index); }))) return rc;
+    if (c->fused.ghist) {
+        // free schedule: histogram, group scan and scatter passes as one sequence; the last pass writes the re-packed index
+        // (the process kernels are done with the old index by then, so it is written in place of it)
+        if (!run_process)
+            RT_HIP(c, hipMemcpyAsync(c->next, c->index, sizeof(rt_index_pair) * size_t(c->pool), hipMemcpyDeviceToDevice, c->stream));
+        rc = timed(c, RT_STAGE_SORT, c->stream, [&] {
+            launch_fused(c->stream, c->ws, c->fused, c->compact, c->glob, c->grp_data, c->next, c->index, c->pool, c->group_count);
+        });
+        if (rc) return rc;
+    } else {
+        rc = timed(c, RT_STAGE_SORT, c->stream, [&] {
+            launch_sort(c->stream, c->ws, run_process ? c->next : c->index, c->sorted, c->pool, &c->glob->g.ray_count, c->group_count,
+                        c->free_schedule);
+        });
+        if (rc) return rc;
+        if ((rc = timed(c, RT_STAGE_COMPACT, c->stream, [&] { launch_compact(l, c->sorted, c->index); }))) return rc;
+    }
     if (c->profiling && c->pending.size() >= 5 * 2048 && (rc = resolve_timers(c))) return rc;
     return check_launch(c, "make_step");
 }
@@ -589,6 +603,12 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     RT_HIP(c, dev_alloc(c->tri_rec, dev_rec.size()));
     RT_HIP(c, dev_alloc(c->grp_data, G));
     RT_HIP(c, alloc_compact(c->compact, G));
+    if (c->free_schedule && G <= kFusedMaxGroups) {
+        RT_HIP(c, dev_alloc(c->fused.ghist, size_t(G) * fused_hist_slices()));
+        RT_HIP(c, dev_alloc(c->fused.block_main, compact_group_blocks(G)));
+        RT_HIP(c, hipMemset(c->fused.ghist, 0, sizeof(uint32_t) * size_t(G) * fused_hist_slices()));
+        RT_HIP(c, fused_setup(G));
+    }
     RT_HIP(c, hipMemset(c->grp, 0, sizeof(rt_group) * size_t(G)));
     RT_HIP(c, hipMemset(c->grp_data, 0, sizeof(rt_group_data) * size_t(G)));
     RT_HIP(c, hipMemcpy(c->grp, dev_grp.data(), sizeof(rt_group) * n_groups, hipMemcpyHostToDevice));

@@ -45,6 +45,18 @@ struct SortWorkspace {
 void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pair *in, rt_index_pair *out,
                  uint32_t count, const uint32_t *n_dev, uint32_t group_count, bool plain_order = false);
 uint32_t sort_key_bits(uint32_t group_count);
+
+// Sort + queue compaction of the free schedule as one sequence (rt_sort.hip): per-group histogram, group
+// scan, scatter passes, the last of which writes the re-packed index.  For at most kFusedMaxGroups groups.
+constexpr uint32_t kFusedMaxGroups = 32768;  // the histogram of a workgroup lives in LDS
+struct FusedWorkspace {
+    uint32_t *ghist;       // [fused_hist_slices()][group_count] entries per group, zero between steps
+    uint32_t *block_main;  // [blocks of kGroupThreads groups] sorted entries per block, then their exclusive prefix sums
+};
+uint32_t fused_hist_slices();
+hipError_t fused_setup(uint32_t group_count);  // once per scene, before the first launch_fused
+void launch_fused(hipStream_t stream, const SortWorkspace &ws, const FusedWorkspace &fw, const CompactWorkspace &cw, DevGlobal *glob,
+                  rt_group_data *grp_data, const rt_index_pair *in, rt_index_pair *out, uint32_t count, uint32_t group_count);
 // Looks up the workspace of rt_sort_pairs_static on the current device (once per device; allocates nothing).
 hipError_t sort_static_setup(void **out);
 

@@ -84,14 +84,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_count(const rt_index_pair *src
     for (uint32_t d = tid; d < kRadix; d += THREADS) counts[d * tiles + tile] = hist[d];
 }
 
-// One block per digit: exclusive scan of that digit's counts over the active tiles, and its total.
-__global__ __launch_bounds__(256) void k_sort_scan(uint32_t *counts, uint32_t *totals, const uint32_t *n_ptr, uint32_t tiles,
-                                                   uint32_t tile_size)
+// One block of 256 threads per digit: exclusive scan of that digit's counts over the active tiles, and its total.
+__device__ __forceinline__ void scan_digit_row(uint32_t *counts, uint32_t *totals, uint32_t n, uint32_t tiles, uint32_t tile_size,
+                                               uint32_t digit, uint32_t *s_wave)
 {
-    __shared__ uint32_t s_wave[4];
-    const uint32_t tid = threadIdx.x, n = *n_ptr;
+    const uint32_t tid = threadIdx.x;
     const uint32_t active = (n + tile_size - 1) / tile_size;
-    uint32_t *row = counts + blockIdx.x * tiles;
+    uint32_t *row = counts + digit * tiles;
     const uint32_t per = (active + 255) / 256;
     const uint32_t first = tid * per < active ? tid * per : active;
     const uint32_t last = first + per < active ? first + per : active;
@@ -104,18 +103,62 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *counts, uint32_t *t
         row[i] = run;
         run += t;
     }
-    if (tid == 0) totals[blockIdx.x] = total;
+    if (tid == 0) totals[digit] = total;
+}
+
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t *counts, uint32_t *totals, const uint32_t *n_ptr, uint32_t tiles,
+                                                   uint32_t tile_size)
+{
+    __shared__ uint32_t s_wave[4];
+    scan_digit_row(counts, totals, *n_ptr, tiles, tile_size, blockIdx.x, s_wave);
 }
 
 // Scatter of one pass.  first_pass: read the tile in the reference's thread-major order.
 // tail_src (final pass only): where pairs at or beyond n are copied from.
-template <uint32_t TILE, uint32_t THREADS>
+// What the final pass of the fused sort + compaction needs to send every pair straight to its place in
+// the re-packed index (set_ray_index, ray-tracer.cl:293-302) instead of to its sorted position.
+struct Placement {
+    const DevGlobal *glob;
+    rt_group_data *grp_data;
+    const GroupMove *move;        // per group: first sorted position inside its block of groups, parked count, offsets inside the block
+    const uint2 *block_sums;      // per block of kGroupThreads groups: whole-warp and parked rays of the blocks before
+    const uint32_t *block_main;   // ... and their sorted entries
+    uint32_t count, group_blocks, tile_blocks;
+};
+
+__device__ __forceinline__ uint32_t placed(const Placement &pl, uint32_t key, uint32_t index, uint32_t old_count, uint32_t all_aligned)
+{
+    const uint32_t g = key & kIdMask;
+    const GroupMove m = pl.move[g];
+    const uint2 block = pl.block_sums[g / kGroupThreads];
+    // position among the group's entries: new ones first, then the ones parked before (ray-tracer.cl:297-298)
+    index -= index < old_count ? pl.block_main[g / kGroupThreads] + m.base0 : m.base1;
+    return index < m.count1 ? index + all_aligned + block.y + m.off1 : index + block.x + m.off0 - m.count1;
+}
+
+template <uint32_t TILE, uint32_t THREADS, bool COMPACT>
 __global__ __launch_bounds__(THREADS) void k_sort_scatter(const rt_index_pair *src, rt_index_pair *dst,
                                                           const rt_index_pair *tail_src, const uint32_t *n_ptr,
                                                           const uint32_t *counts, const uint32_t *totals,
                                                           uint32_t tiles, uint32_t shift, uint32_t mask,
-                                                          uint32_t first_pass)
+                                                          uint32_t first_pass, Placement pl)
 {
+    uint32_t old_count = 0, all_aligned = 0;
+    if (COMPACT) {
+        static_assert(!COMPACT || THREADS == kGroupThreads, "one thread per group of a block");
+        old_count = pl.glob->g.old_count;
+        all_aligned = pl.glob->g.ray_count;
+        if (blockIdx.x < pl.group_blocks) {  // finished entries of this block's groups (ray-tracer.cl:262-289)
+            const uint32_t g = blockIdx.x * kGroupThreads + threadIdx.x;
+            if (g < pl.glob->g.group_count) {
+                const GroupMove m = pl.move[g];
+                const uint2 block = pl.block_sums[blockIdx.x];
+                pl.grp_data[g].base[0] = pl.block_main[blockIdx.x] + m.base0;
+                *reinterpret_cast<uint2 *>(pl.grp_data[g].offset) = make_uint2(block.x + m.off0, all_aligned + block.y + m.off1);
+            }
+        }
+        if (blockIdx.x >= pl.tile_blocks) return;
+    }
     constexpr uint32_t kTile = TILE, kSortThreads = THREADS, kSortWaves = THREADS / 64, kPerThread = TILE / THREADS;
     // The tile, one padding slot after every 16 pairs: the transposing store (stride 16 pairs per
     // thread) and the linear 8-byte reads are then both free of bank conflicts.
@@ -133,7 +176,15 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const rt_index_pair *s
 #pragma unroll 4
         for (uint32_t i = 0; i < kPerThread; i++) {
             const uint32_t p = i * kSortThreads + tid;
-            if (p >= m) dst[base + p] = tail_src[base + p];
+            if (p >= m) {
+                const rt_index_pair e = tail_src[base + p];
+                if (COMPACT) {
+                    const uint32_t at = placed(pl, e.key, base + p, old_count, all_aligned);
+                    if (at < pl.count) dst[at] = e;  // always true for consistent group data
+                } else {
+                    dst[base + p] = e;
+                }
+            }
         }
     }
     if (m == 0) return;
@@ -217,7 +268,13 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const rt_index_pair *s
         const uint32_t j = i * kSortThreads + tid;
         if (j < m) {
             const uint2 e = s_tile[j];
-            dst[s_gbase[(e.x >> shift) & mask] + j] = rt_index_pair{e.x, e.y};
+            const uint32_t at = s_gbase[(e.x >> shift) & mask] + j;
+            if (COMPACT) {
+                const uint32_t to = placed(pl, e.x, at, old_count, all_aligned);
+                if (to < pl.count) dst[to] = rt_index_pair{e.x, e.y};
+            } else {
+                dst[at] = rt_index_pair{e.x, e.y};
+            }
         }
     }
 }
@@ -243,8 +300,8 @@ static void sort_passes(hipStream_t stream, const SortWorkspace &ws, const rt_in
         rt_index_pair *dst = ((passes - 1 - k) % 2 == 0) ? out : ws.tmp;
         k_sort_count<TILE, THREADS><<<tiles, THREADS, 0, stream>>>(src, n_dev, ws.counts, stride, shift, mask);
         k_sort_scan<<<mask + 1, 256, 0, stream>>>(ws.counts, ws.totals, n_dev, stride, TILE);
-        k_sort_scatter<TILE, THREADS><<<tiles, THREADS, 0, stream>>>(src, dst, final_pass ? in : nullptr, n_dev, ws.counts,
-                                                                     ws.totals, stride, shift, mask, k == 0 && thread_major ? 1u : 0u);
+        k_sort_scatter<TILE, THREADS, false><<<tiles, THREADS, 0, stream>>>(src, dst, final_pass ? in : nullptr, n_dev, ws.counts, ws.totals,
+                                                                            stride, shift, mask, k == 0 && thread_major ? 1u : 0u, Placement{});
         src = dst;
     }
 }
@@ -264,6 +321,188 @@ void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pai
     }
     if (plain_order) sort_passes<kSmallTile, kSmallThreads>(stream, ws, in, out, count, n_dev, bits, passes, false);
     else sort_passes<kTile, kSortThreads>(stream, ws, in, out, count, n_dev, bits, passes, true);
+}
+
+// ---------------------------------------------------------------- sort + compaction in one sequence (free schedule)
+//
+// The reference sorts (three launches per pass), then finds the group boundaries in the sorted list,
+// scans the groups and moves every pair a second time (count_groups, update_groups, set_ray_index).
+// With the order free, the group sizes do not have to wait for the sort: one read of the new keys gives
+// the per-group histogram together with the first pass's tile counts, the group scan runs before the
+// scatter passes, and the final pass writes every pair straight to its re-packed place.  Five launches
+// (histogram, groups + digit scan, scatter, count + scan, final scatter) instead of eight.
+
+constexpr uint32_t kHistSlices = 4;  // copies of the group histogram, so that a big group's counter takes a quarter of the atomics
+
+// Per-group histogram of the first n keys, one small tile per workgroup: counted in LDS, then one atomic
+// per non-empty group into the workgroup's slice of the global histogram.  The tile's digit counts for
+// the first pass are sums of its group counts.  s_mem: [groups][256 digits].
+__global__ __launch_bounds__(kSmallThreads) void k_fused_hist(const rt_index_pair *src, DevGlobal *glob, uint32_t *ghist,
+                                                              uint32_t *counts, uint32_t stride, uint32_t groups, uint32_t mask0)
+{
+    extern __shared__ uint32_t s_mem[];
+    uint32_t *s_group = s_mem, *s_digit = s_mem + groups;
+    constexpr uint32_t kPerThread = kSmallTile / kSmallThreads;
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * kSmallTile, n = glob->g.ray_count;
+    if (blockIdx.x == 0 && tid == 0) glob->sort_count = n;  // the passes run after the live count has been replaced
+    if (base >= n) return;
+    uint32_t keys[kPerThread];
+#pragma unroll
+    for (uint32_t i = 0; i < kPerThread; i++) {
+        const uint32_t p = base + i * kSmallThreads + tid;
+        keys[i] = p < n ? src[p].key : 0xFFFFFFFFu;
+    }
+    for (uint32_t i = tid; i < groups + kRadix; i += kSmallThreads) s_mem[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kPerThread; i++) {
+        bool todo = base + i * kSmallThreads + tid < n;
+        uint32_t id = keys[i] & kIdMask;
+        id = id < groups ? id : groups - 1;
+        // Neighbouring rays mostly move on to the same few nodes; 64 LDS atomics on one word would run one
+        // after the other.  The two most likely values are counted with a ballot each, the rest one by one.
+#pragma unroll
+        for (int round = 0; round < 2; round++) {
+            const unsigned long long left = __ballot(todo);
+            if (!left) break;
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)id, (int)(__ffsll((long long)left) - 1));
+            const unsigned long long same = __ballot(todo && id == first);
+            if (todo && id == first) {
+                todo = false;
+                if ((tid & 63) == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&s_group[first], (uint32_t)__popcll(same));
+            }
+        }
+        if (todo) atomicAdd(&s_group[id], 1u);
+    }
+    __syncthreads();
+    uint32_t *slice = ghist + (blockIdx.x % kHistSlices) * groups;
+    for (uint32_t g = tid; g < groups; g += kSmallThreads) {
+        const uint32_t c = s_group[g];
+        if (c) {
+            atomicAdd(&slice[g], c);
+            atomicAdd(&s_digit[g & mask0], c);
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < kRadix; d += kSmallThreads) counts[d * stride + blockIdx.x] = s_digit[d];
+}
+
+// update_groups (ray-tracer.cl:255-290) from the histogram: one thread per group, block-wide prefix sums,
+// the last block to finish scans the block totals and updates the frame counters.  The workgroups
+// beyond the group blocks scan the first pass's tile counts, one digit each.
+__global__ __launch_bounds__(kGroupThreads) void k_fused_groups(DevGlobal *glob, rt_group_data *grp_data, uint32_t *ghist,
+                                                                 CompactWorkspace ws, uint32_t *block_main, uint32_t group_blocks,
+                                                                 uint32_t *counts, uint32_t *totals, uint32_t stride)
+{
+    __shared__ uint32_t s_wave[kGroupThreads / 64];
+    __shared__ bool s_last;
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x >= group_blocks) {
+        scan_digit_row(counts, totals, glob->sort_count, stride, kSmallTile, blockIdx.x - group_blocks, s_wave);
+        return;
+    }
+    const uint32_t g = blockIdx.x * kGroupThreads + tid;
+    const uint32_t groups = glob->g.group_count, n = glob->sort_count;
+    uint32_t main_count = 0, aligned = 0, tail = 0;
+    rt_group_data grp = rt_group_data{{0, 0}, {0, 0}, {0, 0}};
+    if (g < groups) {
+        for (uint32_t k = 0; k < kHistSlices; k++) {
+            main_count += ghist[k * groups + g];
+            ghist[k * groups + g] = 0;  // ready for the next step
+        }
+        grp = grp_data[g];
+        const uint32_t total = main_count + grp.count[1];
+        tail = g != groups - 1 ? total % glob->warp_width : total;  // the last group is the dead-ray bin
+        aligned = total - tail;
+    }
+    uint32_t sum_main, sum_aligned, sum_tail;
+    const uint32_t before_main = block_exclusive_scan<kGroupThreads>(main_count, s_wave, sum_main);
+    const uint32_t before_aligned = block_exclusive_scan<kGroupThreads>(aligned, s_wave, sum_aligned);
+    const uint32_t before_tail = block_exclusive_scan<kGroupThreads>(tail, s_wave, sum_tail);
+    if (g < groups) {
+        ws.move[g] = GroupMove{before_main, grp.offset[1] - main_count, tail, before_aligned, before_tail, {0, 0, 0}};
+        grp_data[g].base[1] = grp.offset[1] - main_count;
+        *reinterpret_cast<uint2 *>(grp_data[g].count) = make_uint2(aligned, tail);
+    }
+    if (g == 0) ws.block_sums[group_blocks] = make_uint2(aligned, 0);  // whole warps of group 0: the next step's new pixels
+
+    // The last block to get here owns the block totals.
+    if (tid == 0) {
+        ws.block_sums[blockIdx.x] = make_uint2(sum_aligned, sum_tail);
+        block_main[blockIdx.x] = sum_main;
+        __threadfence();
+        s_last = atomicAdd(ws.ticket, 1u) == group_blocks - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    uint32_t carry[3] = {0, 0, 0};
+    for (uint32_t first = 0; first < group_blocks; first += kGroupThreads) {
+        const bool in = first + tid < group_blocks;
+        const uint2 sums = in ? ws.block_sums[first + tid] : make_uint2(0, 0);
+        const uint32_t v[3] = {in ? block_main[first + tid] : 0u, sums.x, sums.y};
+        uint32_t excl[3], all[3];
+        for (int k = 0; k < 3; k++) excl[k] = block_exclusive_scan<kGroupThreads>(v[k], s_wave, all[k]);
+        if (in) {
+            block_main[first + tid] = carry[0] + excl[0];
+            ws.block_sums[first + tid] = make_uint2(carry[1] + excl[1], carry[2] + excl[2]);
+        }
+        for (int k = 0; k < 3; k++) carry[k] += all[k];
+    }
+    if (tid == 0) {
+        glob->g.pixel_offset += glob->g.pixel_count;
+        glob->g.pixel_count = ws.block_sums[group_blocks].x;
+        glob->g.old_count = n;
+        glob->g.ray_count = carry[1];  // all whole warps; the parked rays follow them
+        glob->spill_count = 0;
+        *ws.ticket = 0;
+    }
+}
+
+uint32_t fused_hist_slices() { return kHistSlices; }
+
+uint32_t fused_hist_lds_bytes(uint32_t group_count)
+{
+    return (group_count + kRadix) * sizeof(uint32_t);
+}
+
+hipError_t fused_setup(uint32_t group_count)
+{
+    const uint32_t bytes = fused_hist_lds_bytes(group_count);
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+void launch_fused(hipStream_t stream, const SortWorkspace &ws, const FusedWorkspace &fw, const CompactWorkspace &cw, DevGlobal *glob,
+                  rt_group_data *grp_data, const rt_index_pair *in, rt_index_pair *out, uint32_t count, uint32_t group_count)
+{
+    uint32_t bits = 0;
+    while (bits < 24 && ((group_count - 1) >> bits)) bits++;
+    if (bits == 0) bits = 1;
+    const uint32_t passes = (bits + kRadixBits - 1) / kRadixBits;  // 1 or 2: the fused path is for at most kFusedMaxGroups groups
+    const uint32_t digit_bits = (bits + passes - 1) / passes;
+    const uint32_t mask0 = (1u << digit_bits) - 1;
+    const uint32_t tiles = count / kSmallTile, stride = ws.tiles * kSortCountsPerTile;
+    const uint32_t group_blocks = compact_group_blocks(group_count);
+    const uint32_t *n_dev = &glob->sort_count;
+    const Placement pl{glob, grp_data, cw.move, cw.block_sums, fw.block_main, count, group_blocks, tiles};
+    const uint32_t final_grid = tiles > group_blocks ? tiles : group_blocks;
+
+    k_fused_hist<<<tiles, kSmallThreads, fused_hist_lds_bytes(group_count), stream>>>(in, glob, fw.ghist, ws.counts, stride, group_count, mask0);
+    k_fused_groups<<<group_blocks + mask0 + 1, kGroupThreads, 0, stream>>>(glob, grp_data, fw.ghist, cw, fw.block_main, group_blocks,
+                                                                          ws.counts, ws.totals, stride);
+    if (passes == 1) {
+        k_sort_scatter<kSmallTile, kSmallThreads, true><<<final_grid, kSmallThreads, 0, stream>>>(in, out, in, n_dev, ws.counts, ws.totals, stride,
+                                                                                                 0, mask0, 0u, pl);
+        return;
+    }
+    k_sort_scatter<kSmallTile, kSmallThreads, false><<<tiles, kSmallThreads, 0, stream>>>(in, ws.tmp, nullptr, n_dev, ws.counts, ws.totals, stride, 0,
+                                                                                         mask0, 0u, Placement{});
+    const uint32_t mask1 = (1u << (bits - digit_bits)) - 1;
+    k_sort_count<kSmallTile, kSmallThreads><<<tiles, kSmallThreads, 0, stream>>>(ws.tmp, n_dev, ws.counts, stride, digit_bits, mask1);
+    k_sort_scan<<<mask1 + 1, 256, 0, stream>>>(ws.counts, ws.totals, n_dev, stride, kSmallTile);
+    k_sort_scatter<kSmallTile, kSmallThreads, true><<<final_grid, kSmallThreads, 0, stream>>>(ws.tmp, out, in, n_dev, ws.counts, ws.totals, stride,
+                                                                                             digit_bits, mask1, 0u, pl);
 }
 
 }  // namespace rtd
