@@ -498,8 +498,10 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     auto shader_of = [](uint32_t id) { return (id >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK; };
     std::vector<uint8_t> kind(n_groups, 0xFF);
     std::vector<uint32_t> work;
+    bool any_ortho = false;
     auto visit = [&](uint32_t id, const char *where) -> int {
         const uint32_t gi = id & RT_GROUP_ID_MASK, sh = shader_of(id);
+        if (((id >> RT_GROUP_TR_SHIFT) & RT_GROUP_TR_MASK) == RT_TR_ORTHO) any_ortho = true;
         if (gi >= n_groups) return fail(c, RT_ERR_INVALID_VALUE, "%s refers to group %u of %zu", where, gi, n_groups);
         if (sh != RT_SH_AABB && sh != RT_SH_MESH) return fail(c, RT_ERR_INVALID_VALUE, "%s: group %u is not a box or mesh group", where, gi);
         if (kind[gi] == 0xFF) {
@@ -537,8 +539,8 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
             const rt_aabb_shader &s = g.aabb;
             if (uint64_t(s.aabb_offs) + s.aabb_count > n_aabb)
                 return fail(c, RT_ERR_INVALID_VALUE, "group %u: boxes [%u, +%u) exceed %zu", id & RT_GROUP_ID_MASK, s.aabb_offs, s.aabb_count, n_aabb);
-            if (s.aabb_count > 256)
-                return fail(c, RT_ERR_UNSUPPORTED, "group %u has %u boxes; at most 256 per group are supported", id & RT_GROUP_ID_MASK, s.aabb_count);
+            if (s.aabb_count > kMaxListBoxes)
+                return fail(c, RT_ERR_UNSUPPORTED, "group %u has %u boxes; at most %u per group are supported", id & RT_GROUP_ID_MASK, s.aabb_count, kMaxListBoxes);
             for (uint32_t i = 0; i < s.aabb_count; i++) {
                 const rt_aabb &b = aabb[s.aabb_offs + i];
                 if ((rc = visit(b.group_id, "a box"))) return rc;
@@ -550,7 +552,8 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
             dev_boxes.insert(dev_boxes.end(), aabb + s.aabb_offs, aabb + s.aabb_offs + s.aabb_count);
             while (dev_boxes.size() % 8) dev_boxes.push_back(never);
             // clusters of the list: [bounds, filled up to a multiple of four][membership masks, if any]
-            const ClusterSet set = build_clusters(aabb + s.aabb_offs, s.aabb_count);
+            // (a list of more than kMaxClusteredBoxes boxes gets no clusters: every visit of it is left to the one-ray-per-wave kernel)
+            const ClusterSet set = s.aabb_count <= kMaxClusteredBoxes ? build_clusters(aabb + s.aabb_offs, s.aabb_count) : ClusterSet{};
             const uint32_t clusters = uint32_t(set.bounds.size());
             entry[2] = (s.flags & 0xFFu) | clusters << kClusterCountShift | (set.masks.empty() ? 0u : kClusterMasked);
             entry[3] = uint32_t(dev_clusters.size());
@@ -570,6 +573,10 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
             }
             const uint32_t mid = s.material_id & RT_GROUP_ID_MASK;
             if (mid >= n_groups) return fail(c, RT_ERR_INVALID_VALUE, "group %u: material group %u of %zu", id & RT_GROUP_ID_MASK, mid, n_groups);
+            // The group a ray goes to after a hit is run as a shader.  A box or leaf group there would be entered
+            // without having been checked and re-laid out above, so it is not accepted.
+            if (shader_of(s.material_id) > RT_SH_MATERIAL)
+                return fail(c, RT_ERR_INVALID_VALUE, "group %u: its material group %u is not a spawn, sky, light or material group", id & RT_GROUP_ID_MASK, mid);
             const size_t at = dev_tri.size();
             dev_grp[id & RT_GROUP_ID_MASK].mesh.tri_offs = uint32_t(at);
             dev_tri.insert(dev_tri.end(), tri + s.tri_offs, tri + s.tri_offs + s.tri_count);
@@ -586,7 +593,9 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     dev_tri.insert(dev_tri.end(), 6, 0u);
     dev_rec.insert(dev_rec.end(), 6, null_tri);
     if (dev_boxes.size() > 0x7FFFFFFFu || dev_tri.size() > 0x7FFFFFFFu) return fail(c, RT_ERR_UNSUPPORTED, "scene too large");
-    if (((data->cam.root_group >> RT_GROUP_TR_SHIFT) & RT_GROUP_TR_MASK) == RT_TR_ORTHO && data->cam.root_local >= n_mat)
+    // A group entered with an instance transform takes its matrix from the ray's first local id: the number a box
+    // of an instance list gave it (checked above), or else the camera's.
+    if (any_ortho && data->cam.root_local >= n_mat)
         return fail(c, RT_ERR_INVALID_VALUE, "camera root instance %u of %zu matrices", data->cam.root_local, n_mat);
 
     RT_HIP(c, hipSetDevice(c->cfg.device));
@@ -773,21 +782,23 @@ int rt_sort_pairs(rt_ctx *c, const rt_index_pair *in, rt_index_pair *out, uint32
     RT_HIP(c, hipSetDevice(c->cfg.device));
     const size_t bytes = sizeof(rt_index_pair) * size_t(count);
     rt_index_pair *d_in = nullptr, *d_out = nullptr;
+    int rc = RT_OK;
+    auto step = [&](hipError_t err, const char *what) {
+        if (err != hipSuccess && !rc) rc = fail(c, err == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+    };
     if (!on_device) {
-        RT_HIP(c, dev_alloc(d_in, count));
-        RT_HIP(c, dev_alloc(d_out, count));
-        RT_HIP(c, hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, c->stream));
+        step(dev_alloc(d_in, count), "alloc");
+        step(dev_alloc(d_out, count), "alloc");
+        if (!rc) step(hipMemcpyAsync(d_in, in, bytes, hipMemcpyHostToDevice, c->stream), "upload");
     }
-    RT_HIP(c, set_global_field(c, offsetof(DevGlobal, sort_count), &n, sizeof(n)));
-    launch_sort(c->stream, c->ws, on_device ? in : d_in, on_device ? out : d_out, count, &c->glob->sort_count, group_count,
-                c->free_schedule);
-    int rc = check_launch(c, "sort");
-    if (!on_device && !rc) {
-        const hipError_t err = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream);
-        if (err != hipSuccess) rc = fail(c, RT_ERR_HIP, "copy back: %s", hipGetErrorString(err));
+    if (!rc) step(set_global_field(c, offsetof(DevGlobal, sort_count), &n, sizeof(n)), "count");
+    if (!rc) {
+        launch_sort(c->stream, c->ws, on_device ? in : d_in, on_device ? out : d_out, count, &c->glob->sort_count, group_count,
+                    c->free_schedule);
+        rc = check_launch(c, "sort");
     }
-    const hipError_t err = hipStreamSynchronize(c->stream);
-    if (err != hipSuccess && !rc) rc = fail(c, RT_ERR_HIP, "sort: %s", hipGetErrorString(err));
+    if (!on_device && !rc) step(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, c->stream), "copy back");
+    step(hipStreamSynchronize(c->stream), "sort");  // also: n is read from this call's frame until the copy has run
     dev_free(d_in);
     dev_free(d_out);
     return rc;
@@ -853,6 +864,7 @@ int rt_dump_state(rt_ctx *c, rt_ray_queue *ray_list, rt_index_pair *ray_index, r
     RT_HIP(c, hipSetDevice(c->cfg.device));
     if (ray_list) {
         rt_ray_queue *d_out = nullptr;
+        RT_HIP(c, hipStreamSynchronize(c->stream));
         RT_HIP(c, dev_alloc(d_out, c->pool));
         launch_export_rays(launch_ctx(c), d_out);
         const hipError_t err = hipMemcpyAsync(ray_list, d_out, sizeof(rt_ray_queue) * size_t(c->pool), hipMemcpyDeviceToHost, c->stream);
@@ -885,12 +897,17 @@ int rt_trace_closest(rt_ctx *c, const rt_ray *rays, uint32_t n_rays, rt_hit_reco
 
     rt_ray *d_rays = nullptr;
     rt_hit_record *d_hits = nullptr, *saved_hits = c->hits;
-    RT_HIP(c, dev_alloc(d_rays, n_rays));
-    RT_HIP(c, dev_alloc(d_hits, n_rays));
     int rc = RT_OK;
     auto step = [&](hipError_t err, const char *what) {
-        if (err != hipSuccess && !rc) rc = fail(c, RT_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+        if (err != hipSuccess && !rc) rc = fail(c, err == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
     };
+    step(dev_alloc(d_rays, n_rays), "alloc");
+    step(dev_alloc(d_hits, n_rays), "alloc");
+    if (rc) {
+        dev_free(d_rays);
+        dev_free(d_hits);
+        return rc;
+    }
     // sample ids 0..n-1 get a hit record, later ids are parked; granularity 1; shaders park the ray
     const uint32_t settings[5] = {1u, n_rays ? n_rays : 1u, n_rays, c->cfg.row_offset, kModeTraceOnly};
     step(set_global_field(c, offsetof(DevGlobal, warp_width), settings, sizeof(settings)), "settings");

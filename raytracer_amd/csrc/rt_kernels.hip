@@ -516,7 +516,7 @@ __device__ __forceinline__ float lane_value(float v, uint32_t lane)
 // are this wave's 64-entry scratch lists in LDS.  Returns the candidate count (0 when more than 64
 // boxes are accepted: the reference gives up on the whole node), the list is left sorted.
 __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t count, const V3 start, const V3 inv_dir,
-                                                   float ray_min, float ray_max, float *c_pos, uint8_t *c_idx)
+                                                   float ray_min, float ray_max, float *c_pos, uint16_t *c_idx)
 {
     const unsigned long long active = __ballot(true);
     const unsigned long long below = (1ull << lane_id()) - 1;
@@ -537,7 +537,7 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
         const uint32_t at = total + __popcll(m & below);
         if (hit && at < RT_MAX_HITS) {
             c_pos[at] = t;
-            c_idx[at] = (uint8_t)i;
+            c_idx[at] = (uint16_t)i;
         }
         total += __popcll(m);
     }
@@ -545,7 +545,7 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
     auto exchange = [&](uint32_t j, uint32_t i) {
         const float pj = c_pos[j], pi = c_pos[i];
         if (pj > pi) {
-            const uint8_t ij = c_idx[j], ii = c_idx[i];
+            const uint16_t ij = c_idx[j], ii = c_idx[i];
             c_pos[j] = pi;  c_pos[i] = pj;
             c_idx[j] = ii;  c_idx[i] = ij;
         }
@@ -578,7 +578,7 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
 // only the lane `owner` merges and stores.
 template <int CAP, int THREADS, bool COOP>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
-                                           uint8_t (*s_idx)[THREADS], float *c_pos, uint8_t *c_idx, uint32_t owner,
+                                           uint8_t (*s_idx)[THREADS], float *c_pos, uint16_t *c_idx, uint32_t owner,
                                            uint32_t tid, uint32_t &new_key, uint32_t &group_flags)
 {
     AABB_STAMP(t_start);
@@ -607,6 +607,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     // in the order the reference's loop does (shader.cl:84-99).  The device copies of both lists are
     // filled up with entries no ray can enter and followed by readable spare entries: the loops have
     // no tail handling and always have the next 128 bytes in flight while the current ones are tested.
+    if (count > kMaxClusteredBoxes) return false;  // places in such a list do not fit the columns' bytes
     asm volatile("" ::"v"(inv_dir.x), "v"(inv_dir.y), "v"(inv_dir.z), "v"(lr.start.x));
     AABB_STAMP(t_loaded);
     bool spill = false;
@@ -947,7 +948,7 @@ template <bool FREE>
 __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a, const uint32_t *spill_list)
 {
     __shared__ float s_wave_pos[kBigThreads / 64][RT_MAX_HITS];   // per wave: the lists of wave_visit_one
-    __shared__ uint8_t s_wave_idx[kBigThreads / 64][RT_MAX_HITS];
+    __shared__ uint16_t s_wave_idx[kBigThreads / 64][RT_MAX_HITS];
     const uint32_t tid = threadIdx.x, wave = tid / 64;
     const uint32_t total = a.frame.glob->spill_count;
     for (uint32_t at = blockIdx.x * (kBigThreads / 64) + wave; at < total; at += kBigBlocks * (kBigThreads / 64)) {

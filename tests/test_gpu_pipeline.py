@@ -261,6 +261,34 @@ def test_incoherent_rays_in_a_grid_of_instances(standin_ply):
     rt.close(); o.close()
 
 
+def test_instance_list_longer_than_256_boxes():
+    """A 7x7x7 grid puts 343 boxes under the scene root: more than the box kernel's one-byte places hold, so
+    every root visit is done by the one-ray-per-wave kernel.  Hits bit-exact against the oracle, either schedule."""
+    from oracle import pyoracle as O
+    sc = S.build_scene([S.BUNNY], 64, 64, 16384, grid=7)
+    root = int(sc.data["cam"]["root_group"][0]) & L.GROUP_ID_MASK
+    first, count = int(sc.groups["w"][root][0]), int(sc.groups["w"][root][1])
+    assert count == 343
+    boxes = sc.aabbs[first:first + count]
+    lo, hi = boxes["min"].min(axis=0), boxes["max"].max(axis=0)
+    rng = np.random.default_rng(343)
+    n = 6000
+    rays = np.zeros(n, L.ray_dtype)
+    rays["start_min"][:, :3] = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    rays["start_min"][:, 3] = 0.001
+    d = rng.normal(size=(n, 3))
+    rays["dir_max"][:, :3] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["dir_max"][:, 3] = np.inf
+    o = O.Oracle(sc, warp_width=32, threads=8)
+    want = o.trace_closest(rays)
+    o.close()
+    assert 0.01 < np.isfinite(want["t"]).mean() < 1.0
+    for free in (False, True):
+        rt = api.RayTracer(sc, warp_width=64, free_schedule=free)
+        assert H.same_bytes(rt.trace_closest(rays), want), free
+        rt.close()
+
+
 def test_api_errors(bunny_scene_64):
     rt = api.RayTracer(bunny_scene_64)
     with pytest.raises(api.RtError, match="RT_ERR_NOT_READY"):
