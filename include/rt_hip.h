@@ -100,7 +100,7 @@ typedef struct { float start_min[4]; float dir_max[4]; } rt_ray;
 
 typedef struct {
     uint64_t primary_spawned; /* samples started: sum of pixel_count, cf. main.cpp:538-540 */
-    uint64_t shadow_spawned;  /* mat_shader invocations (shader.cl:20-35) */
+    uint64_t shadow_spawned;  /* secondary rays started: mat_shader invocations (shader.cl:20-35), shadow rays and bounces alike */
     uint64_t steps;           /* make_step calls so far */
     uint64_t box_tests;       /* boxes scanned by aabb_shader, summed over rays (shader.cl:84-99) */
     uint64_t tri_tests;       /* triangles scanned by mesh_shader, summed over rays (shader.cl:123-133) */
@@ -133,6 +133,21 @@ typedef struct {
  * of as a step of their own, and a finished slot is re-initialised and sent through the scene root in one
  * launch.  Without it (0) every step reproduces the reference's make_step exactly. */
 #define RT_FLAG_FREE_SCHEDULE 1u
+
+/* Shading beyond the reference's one shadow ray per sample, also in rt_config.flags: bits 8-11 say what a
+ * material group does with a sample that has hit it, bits 12-15 how many times (bounces), bits 16-31 seed
+ * the random directions.  After `bounces` bounces, and always with RT_SHADE_REFERENCE, a hit is shaded as
+ * the reference compiles it: direct light through one shadow ray (mat_shader, shader.cl:20-35).
+ *   RT_SHADE_MIRROR   the reflection the reference left commented out (shader.cl:37-39): the sample goes
+ *                     on from the hit point along dir - 2 dot(dir, n) n with its weight unchanged and
+ *                     ends in the sky group;
+ *   RT_SHADE_DIFFUSE  the sample goes on in a cosine-weighted random direction about the normal (turned
+ *                     towards the side the ray came from), its weight multiplied by the material colour.
+ * The bounce count of a sample is kept in bits 8 and up of RayQueue.type (ray-tracer.h:157-160 uses 0, 1). */
+enum { RT_SHADE_REFERENCE = 0, RT_SHADE_MIRROR = 1, RT_SHADE_DIFFUSE = 2 };
+#define RT_FLAG_SHADING(mode, bounces, seed) \
+    (((uint32_t)(mode) & 15u) << 8 | ((uint32_t)(bounces) & 15u) << 12 | ((uint32_t)(seed) & 0xFFFFu) << 16)
+#define RT_FLAG_SHADING_MASK 0xFFFFFF00u
 
 enum {
     RT_OK = 0,

@@ -75,10 +75,10 @@ def _view(ptr, count, dtype):
 class Oracle:
     """The reference pipeline on the CPU: same calls as raytracer_amd.RayTracer."""
 
-    def __init__(self, scene, warp_width=32, sample_limit=0, hit_capacity=0, threads=1):
+    def __init__(self, scene, warp_width=32, sample_limit=0, hit_capacity=0, threads=1, shading=0):
         self.scene = scene
         cfg = Config(0, scene.width, scene.height, scene.pool_size, warp_width, sample_limit, hit_capacity,
-                     scene.row_offset, 0)
+                     scene.row_offset, shading)
         self.h = lib().orc_create(C.byref(cfg))
         if not self.h:
             raise RuntimeError("orc_create failed")

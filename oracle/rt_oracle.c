@@ -42,6 +42,7 @@ struct orc_ctx {
     uint32_t *tri;
     size_t n_groups, n_mat, n_aabb, n_vtx, n_tri;
     uint32_t *sample_id;
+    uint32_t shading; /* bits 8-31 of rt_config.flags: mode, bounces, seed */
     rt_hit_record *hits;
     rt_counters counters;
     orc_work work;
@@ -158,9 +159,54 @@ static uint32_t sky_or_light_shader(orc_ctx *c, rt_ray_queue *ray, int is_light)
     return ray->queue[0].group_id = RT_SPAWN_GROUP;
 }
 
-/* shader.cl:20-35 */
-static uint32_t mat_shader(rt_ray_queue *ray, const rt_mat_shader *shader)
+/* Counter-based random numbers of the diffuse bounce (beyond the reference; the HIP path uses the same). */
+static uint32_t hash32(uint32_t x)
 {
+    x ^= x >> 16;  x *= 0x7FEB352Du;
+    x ^= x >> 15;  x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+static float uniform01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+/* The bounce a material group performs instead of shading while a sample has bounces left
+ * (rt_config.flags, RT_FLAG_SHADING).  Mirror: the lines the reference left commented out, shader.cl:37-39.
+ * Diffuse: normal (turned towards the incoming side) plus a uniform point of the unit sphere (Marsaglia's
+ * rejection method on hashed counters), normalised; weight times the material colour. */
+static uint32_t bounce_shader(rt_ray_queue *ray, const rt_mat_shader *shader, uint32_t shading, uint32_t depth, uint32_t sample)
+{
+    const v3 dir = v3_load(ray->dir_max), norm = v3_normalize(v3_load(ray->norm));
+    v3 out;
+    if ((shading & 15u) == RT_SHADE_MIRROR) {
+        out = v3_sub(dir, v3_scale(norm, 2 * v3_dot(dir, norm)));
+    } else {
+        const v3 up = v3_dot(dir, norm) > 0 ? v3_make(-norm.x, -norm.y, -norm.z) : norm;
+        const uint32_t base = hash32((shading >> 8) ^ sample * 0x9E3779B9u ^ depth * 0x85EBCA6Bu);
+        float x1 = 0, x2 = 0, s = 0;
+        for (uint32_t k = 0; k < 8; k++) {
+            const float a = 2 * uniform01(hash32(base + 2 * k)) - 1, b = 2 * uniform01(hash32(base + 2 * k + 1)) - 1;
+            const float q = a * a + b * b;
+            if (q < 1) { x1 = a; x2 = b; s = q; break; }
+        }
+        const float r = 2 * sqrtf(1 - s);
+        const v3 v = v3_add(up, v3_make(x1 * r, x2 * r, 1 - 2 * s));
+        const float len2 = v3_dot(v, v);
+        out = len2 > 1e-12f ? v3_scale(v, 1.0f / sqrtf(len2)) : up;
+        ray->weight[0] *= shader->color[0]; ray->weight[1] *= shader->color[1]; ray->weight[2] *= shader->color[2];
+    }
+    ray->type = RT_RAY_PRIMARY | (depth + 1) << 8;
+    v3_store(ray->start_min, v3_add(v3_load(ray->start_min), v3_scale(dir, ray->dir_max[3])));
+    v3_store(ray->dir_max, out);
+    return reset_ray(ray, ray->root.group_id, ray->root.local_id, RT_SKY_GROUP);
+}
+
+/* shader.cl:20-35 */
+static uint32_t mat_shader(rt_ray_queue *ray, const rt_mat_shader *shader, uint32_t shading, uint32_t sample)
+{
+    if (shading & 15u) {
+        const uint32_t depth = ray->type >> 8;
+        if (depth < ((shading >> 4) & 15u)) return bounce_shader(ray, shader, shading, depth, sample);
+    }
     const float l = 0.57735026f; /* normalize((1,-1,1)) */
     const v3 light = v3_make(l, -l, l);
     const float alpha = 100, f0 = 0.04f;
@@ -336,7 +382,7 @@ static void process_one(orc_ctx *c, uint32_t index, rt_index_pair *ray_index, or
 
     case RT_SH_MATERIAL:
         if (c->mode & ORC_TRACE_ONLY) { group_id = ray->queue[0].group_id = dead; break; }
-        group_id = mat_shader(ray, &grp->material);
+        group_id = mat_shader(ray, &grp->material, c->shading, c->sample_id[offs]);
         work->shade_calls++;
         work->shadows++;
         break;
@@ -390,7 +436,7 @@ static void process_one(orc_ctx *c, uint32_t index, rt_index_pair *ray_index, or
             break;
         }
         /* insert_stop, ray-tracer.cl:173-203 */
-        if (ray->type == RT_RAY_SHADOW) {
+        if ((ray->type & 0xFFu) == RT_RAY_SHADOW) { /* (bounce count above the low byte) */
             area_add(c, ray->pixel, 0, 0, 0, ray->weight[3]);
             material_id = RT_SPAWN_GROUP;
         } else {
@@ -402,7 +448,7 @@ static void process_one(orc_ctx *c, uint32_t index, rt_index_pair *ray_index, or
             ray->orig.local_id[0] = ray->queue[0].local_id[0];
             ray->orig.local_id[1] = ray->queue[0].local_id[1];
             const uint32_t sid = c->sample_id[offs];
-            if (sid < c->hit_capacity) {
+            if (ray->type == RT_RAY_PRIMARY && sid < c->hit_capacity) { /* the camera ray's hit; a bounced sample keeps it */
                 rt_hit_record rec = {norm_pos[3], ray->queue[0].group_id, ray->queue[0].local_id[0], hit_tri};
                 c->hits[sid] = rec;
             }
@@ -732,6 +778,7 @@ orc_ctx *orc_create(const rt_config *cfg)
     c->sample_limit = cfg->sample_limit;
     c->hit_capacity = cfg->hit_capacity;
     c->row_offset = cfg->row_offset;
+    c->shading = cfg->flags >> 8;
     c->threads = 1;
     c->area = calloc((size_t)c->area_size * 4, sizeof(float));
     c->ray_list = calloc(c->pool, sizeof(rt_ray_queue));

@@ -396,7 +396,8 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
 {
     if (!cfg || !out) return RT_ERR_INVALID_VALUE;
     *out = nullptr;
-    if (!cfg->width || !cfg->height || !cfg->ray_count || (cfg->flags & ~RT_FLAG_FREE_SCHEDULE)) return RT_ERR_INVALID_VALUE;
+    if (!cfg->width || !cfg->height || !cfg->ray_count || (cfg->flags & ~(RT_FLAG_FREE_SCHEDULE | RT_FLAG_SHADING_MASK))) return RT_ERR_INVALID_VALUE;
+    if (((cfg->flags >> 8) & 15u) > RT_SHADE_DIFFUSE) return RT_ERR_INVALID_VALUE;
     if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) return RT_ERR_INVALID_VALUE;
     if (uint64_t(cfg->ray_count) + RT_SORT_TILE > 0x7FFFFFFFull) return RT_ERR_INVALID_VALUE;
     int n_dev = 0;
@@ -637,6 +638,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     init.sample_limit = c->cfg.sample_limit;
     init.hit_capacity = c->cfg.hit_capacity;
     init.row_offset = c->cfg.row_offset;
+    init.shading = c->cfg.flags >> 8;
     RT_HIP(c, hipMemcpy(c->glob, &init, sizeof(init), hipMemcpyHostToDevice));
     c->scene_ready = true;
     return RT_OK;

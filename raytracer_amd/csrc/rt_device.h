@@ -52,8 +52,9 @@ static_assert(sizeof(TriRecord) == 48, "triangle record must be 48 bytes");
 struct alignas(16) DevGlobal {
     rt_global_data g;
     uint32_t warp_width, sample_limit, hit_capacity, row_offset;
-    uint32_t mode, sort_count, spill_count, pad1;  // sort_count: element count for stand-alone sort calls;
-                                                    // spill_count: box visits left to k_process_aabb_big this step
+    uint32_t mode, sort_count, spill_count, shading;  // sort_count: element count for stand-alone sort calls;
+                                                       // spill_count: box visits left to k_process_aabb_big this step;
+                                                       // shading: bits 8-31 of rt_config.flags shifted down (mode, bounces, seed)
 };
 
 // Queue compaction: what moving an entry of group g needs, and the per-block prefix sums.
@@ -144,6 +145,16 @@ __device__ __forceinline__ float pow100(float x)
     const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32;
     return (x64 * x32) * x4;
 }
+
+// Counter-based random numbers for the diffuse bounce: a 32-bit integer hash of (seed, sample, bounce, draw).
+__device__ __forceinline__ uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16;  x *= 0x7FEB352Du;
+    x ^= x >> 15;  x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float uniform01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
 
 // Pointers into the constant address space: loads through them with a wave-uniform address are
 // scalar loads (s_load_dwordx4/x8), which is how node payload reaches a wave whose lanes all sit in

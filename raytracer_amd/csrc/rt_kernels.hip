@@ -282,8 +282,56 @@ __device__ __forceinline__ uint32_t sky_or_light_shader(const ProcessArgs &a, Ra
     return RT_SPAWN_GROUP;
 }
 
-__device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color)
+// A sample that bounces instead of being shaded (RT_SHADE_MIRROR: shader.cl:37-39; RT_SHADE_DIFFUSE: a
+// cosine-weighted direction, the normal plus a uniform point of the unit sphere, drawn by Marsaglia's
+// rejection method from hashed counters so that it only depends on seed, sample and bounce number).
+__device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, float4 color, uint32_t shading, uint32_t depth)
 {
+    const float4 sm = ray->start_min, dm = ray->dir_max;
+    const V3 dir = xyz(dm), norm = normalize(xyz(ray->norm));
+    V3 out;
+    if ((shading & 15u) == RT_SHADE_MIRROR) {
+        out = dir - norm * (2 * dot(dir, norm));
+    } else {
+        const V3 up = dot(dir, norm) > 0 ? v3(-norm.x, -norm.y, -norm.z) : norm;
+        const uint32_t base = hash32((shading >> 8) ^ ray->sample_id * 0x9E3779B9u ^ depth * 0x85EBCA6Bu);
+        float x1 = 0, x2 = 0, s = 0;
+        for (uint32_t k = 0; k < 8; k++) {
+            const float a = 2 * uniform01(hash32(base + 2 * k)) - 1, b = 2 * uniform01(hash32(base + 2 * k + 1)) - 1;
+            const float q = a * a + b * b;
+            if (q < 1) {
+                x1 = a;  x2 = b;  s = q;
+                break;
+            }
+        }
+        const float r = 2 * sqrtf(1 - s);
+        const V3 v = up + v3(x1 * r, x2 * r, 1 - 2 * s);
+        const float len2 = dot(v, v);
+        out = len2 > 1e-12f ? v * (1.0f / sqrtf(len2)) : up;
+        float4 w = ray->weight;
+        w.x *= color.x;
+        w.y *= color.y;
+        w.z *= color.z;
+        ray->weight = w;
+    }
+    ray->type = RT_RAY_PRIMARY | (depth + 1) << 8;
+    const V3 s0 = xyz(sm) + dir * dm.w;
+    ray->start_min.x = s0.x;
+    ray->start_min.y = s0.y;
+    ray->start_min.z = s0.z;
+    ray->dir_max.x = out.x;
+    ray->dir_max.y = out.y;
+    ray->dir_max.z = out.z;
+    const RayHit root = ray->root;
+    return reset_ray(ray, root.group_id, root.local0, root.local1, RT_SKY_GROUP);
+}
+
+__device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color, uint32_t shading)
+{
+    if (shading & 15u) {
+        const uint32_t depth = ray->type >> 8;
+        if (depth < ((shading >> 4) & 15u)) return bounce_shader(ray, color, shading, depth);
+    }
     const float l = 0.57735026f;
     const V3 light = v3(l, -l, l);
     const float alpha = 100, f0 = 0.04f;
@@ -331,7 +379,7 @@ __device__ __forceinline__ uint32_t run_end_group(uint32_t key, RaySlot *ray, co
     if (shader != RT_SH_MATERIAL) return sky_or_light_shader(a, ray, shader == RT_SH_LIGHT);
     const float4 color = *reinterpret_cast<const float4 *>(a.scene.grp + (key & kIdMask));
     count_lanes(a.frame, kShadowSpawned, true);
-    return mat_shader(ray, color);
+    return mat_shader(ray, color, a.frame.glob->shading);
 }
 
 // ---------------------------------------------------------------- leaf visit (shader.cl:115-139, ray-tracer.cl:149-203)
@@ -409,7 +457,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
         q[i] = RayHit{0.0f, 0u, 0u, 0u};
         if ((uint32_t)i < queue_len) q[i] = ray->queue[i];
     }
-    const bool hit = hit_index != 0xFFFFFFFFu, shadow = meta.y == RT_RAY_SHADOW;
+    const bool hit = hit_index != 0xFFFFFFFFu, shadow = (meta.y & 0xFFu) == RT_RAY_SHADOW;  // (bounce count above the low byte)
     uint32_t len = queue_len - 1, end_group = meta.z, sid = 0xFFFFFFFFu;
     float shadow_weight = 0;
     V3 nw = v3(0, 0, 0);
@@ -442,7 +490,8 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
             ray->dir_max.w = best;
             ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
             ray->hit_tri = hit_index;
-            if (sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
+            // the record is the camera ray's hit: a sample that has bounced keeps it
+            if (meta.y == RT_RAY_PRIMARY && sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
         }
         ray->material_id = end_group;
     }
@@ -1046,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
                 break;
             }
             const f32x4 color = *const_ptr<f32x4>(a.scene.grp + (g & kIdMask));
-            new_key = mat_shader(ray, make_float4(color.x, color.y, color.z, color.w));
+            new_key = mat_shader(ray, make_float4(color.x, color.y, color.z, color.w), glob->shading);
             count_lanes(a.frame, kShadowSpawned, true);
             break;
         }
