@@ -22,6 +22,7 @@ events inside the timed steps instead).  `cpu_baseline` is the CPU restatement o
 kernels (oracle/) on the host cores, on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -51,6 +52,17 @@ def parse():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--scene", default="bunny+dragon", choices=["bunny+dragon", "bunny", "dragon"])
+    p.add_argument("--grid", type=int, default=0,
+                   help="k > 0: a regular k*k*k grid of instances instead of the reference's random field of 256 (the "
+                        "incoherent workload: --scene dragon --grid 5 --shading diffuse keeps 109 M triangles instanced)")
+    p.add_argument("--shading", default="reference", choices=["reference", "mirror", "diffuse"],
+                   help="what a material does with a sample: the reference's direct light + shadow ray, or --bounces "
+                        "mirror / cosine-weighted diffuse bounces first (RT_FLAG_SHADING)")
+    p.add_argument("--bounces", type=int, default=2)
+    p.add_argument("--settle", type=int, default=96,
+                   help="untimed steps run before the --warmup steps, whatever --warmup says: after rt_init_frame every ray "
+                        "starts at the scene root in lock-step, and the rate only means something once the pool has mixed")
+    p.add_argument("--no-extras", action="store_true", help="skip the extra configurations and the band prediction (N = 1 only)")
     p.add_argument("--warp-width", type=int, default=64)
     p.add_argument("--schedule", default="free", choices=["free", "reference"],
                    help="free: RT_FLAG_FREE_SCHEDULE (any processing order, same per-sample results); reference: every "
@@ -119,6 +131,55 @@ def cpu_baseline(args, files, seconds):
                       f"WARP_WIDTH 32, {warm} warm-up + {timed} timed steps, OpenMP over work-groups"}
 
 
+def shading_flags(args):
+    mode = {"reference": api.SHADE_REFERENCE, "mirror": api.SHADE_MIRROR, "diffuse": api.SHADE_DIFFUSE}[args.shading]
+    return api.shading_flags(mode, args.bounces) if mode else 0
+
+
+def settle(rt, steps):
+    """Runs `steps` untimed steps, then more (up to as many again) until the number of samples started per
+    step has stopped drifting: under 2 % between two windows of 8 steps.  Returns (steps run, steady)."""
+    rt.make_step(steps)
+    done, last = steps, None
+    while done < 2 * steps + 16:
+        c0 = rt.counters()
+        rt.make_step(8)
+        c1 = rt.counters()
+        done += 8
+        rate = int(c1["primary_spawned"]) - int(c0["primary_spawned"])
+        if last is not None and abs(rate - last) <= 0.02 * max(rate, last, 1):
+            return done, True
+        last = rate
+    return done, False
+
+
+def quick_rate(files, width, height, args, device, band=(0, 0), steps=32):
+    """Mrays/s and ms/step of one more configuration on this GPU (settled, `steps` timed steps)."""
+    pool = S.L.align_up(width * height, S.L.SORT_TILE)
+    sc = S.build_scene(files, width, height, pool, band_first=band[0], band_rows=band[1], grid=args.grid)
+    rt = api.RayTracer(sc, device=device, warp_width=args.warp_width, free_schedule=args.schedule == "free",
+                       shading=shading_flags(args))
+    rt.init_frame()
+    _, steady = settle(rt, args.settle)
+    rt.sync()
+    c0 = rt.counters()
+    t0 = time.perf_counter()
+    rt.make_step(steps)
+    rt.draw_frame_device()
+    rt.sync()
+    dt = time.perf_counter() - t0
+    c1 = rt.counters()
+    rt.close()
+    rays = int(c1["primary_spawned"]) - int(c0["primary_spawned"]) + int(c1["shadow_spawned"]) - int(c0["shadow_spawned"])
+    return {"mrays_per_s": rays / dt / 1e6, "ms_per_step": dt * 1e3 / steps, "steady": steady, "pool": pool, "groups": sc.group_count}
+
+
+def library_digest():
+    path = os.environ.get("RT_HIP_LIB", api.HIP_LIB_PATH)
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -147,8 +208,9 @@ def main():
     first, rows = tiling.band_of(rank, world, args.height)
     pool = S.L.align_up(args.width * args.height, S.L.SORT_TILE)
     sc = S.build_scene(files, args.width, args.height, pool, band_first=first, band_rows=rows,
-                       tri_threshold=args.tri_threshold, aabb_threshold=args.aabb_threshold)
-    rt = api.RayTracer(sc, device=device, warp_width=args.warp_width, free_schedule=args.schedule == "free")
+                       tri_threshold=args.tri_threshold, aabb_threshold=args.aabb_threshold, grid=args.grid)
+    rt = api.RayTracer(sc, device=device, warp_width=args.warp_width, free_schedule=args.schedule == "free",
+                       shading=shading_flags(args))
     rt.init_frame()
 
     band = frame = None
@@ -178,6 +240,7 @@ def main():
             if tensor_device == "cuda":
                 torch.cuda.synchronize()
 
+    settled, steady = settle(rt, args.settle)
     rt.make_step(args.warmup)
     barrier()
     t_g = time.perf_counter()
@@ -237,11 +300,15 @@ def main():
         else:
             alg_flop = FLOP_PER_SHADE * (dk["primary_spawned"] + dk["shadow_spawned"]) / args.steps
         seconds = max(per_launch[dominant] * 1e-3, 1e-12)
+        # HBM bytes per launch from the hardware counters (tools/pmc.py + pmc_report.py, separate rocprofv3 --pmc
+        # passes): only quoted when they were collected on this very build of the library and this schedule
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(kernel)
+                t = json.load(open(tfile))
+                if t.get("library_sha256") == library_digest() and t.get("schedule") == args.schedule:
+                    traffic = t["kernels"].get(kernel)
             except Exception:
                 traffic = None
         hbm = alg_bytes / seconds / 1e9
@@ -260,10 +327,13 @@ def main():
         out = {
             "metric": "Mrays/s (primary+secondary), dragon_vrip 1080p, at 1/2/4/8 MI355X",
             "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "settle_steps": settled, "steady": steady,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{label}, 256 instances (reference scene), {args.width}x{args.height}, "
-                                   f"{pool} ray slots per GPU, primary + shadow rays",
+            "config": {"workload": f"{label}, " + (f"{args.grid}^3 grid of instances" if args.grid else "256 instances (reference scene)")
+                                   + f", {args.width}x{args.height}, {pool} ray slots per GPU, "
+                                   + ("primary + shadow rays" if args.shading == "reference" else
+                                      f"primary rays, {args.bounces} {args.shading} bounces, shadow rays"),
                        "tiling": f"{world} row band(s), RGBA8 all-gather per frame" if world > 1 else "single GPU",
                        "warp_width": args.warp_width, "schedule": args.schedule, "groups": sc.group_count,
                        "tri_threshold": args.tri_threshold, "aabb_threshold": args.aabb_threshold},
@@ -271,7 +341,31 @@ def main():
             "stage_ms_per_step": per_launch, "stage_timers": args.stage_timers, "schedule": "serial" if args.serial else "leaf kernel on a second stream", "frame_resolve_gather_ms": gather_ms,
             "frame_resolve_to_host_ms": readback_ms,
             "roofline": roof[0], "roofline_other_bound": roof[1],
+            "scene_build": {"ingest_seconds": sc.ingest_seconds, "hierarchy_and_assembly_seconds": sc.build_seconds,
+                            "model_files_from_binary_cache": sc.models_from_cache, "resident_triangles": sc.resident_triangles},
         }
+        if world == 1 and not args.no_extras:
+            rt.close()  # one full-size pool at a time
+            extra = {"configs": {}}
+            try:
+                if (args.width, args.height) != (3840, 2160):
+                    extra["configs"]["3840x2160, same scene"] = quick_rate(files, 3840, 2160, args, device)
+                if args.scene != "bunny":
+                    extra["configs"][f"{args.width}x{args.height}, bun_zipper x2"] = quick_rate([S.BUNNY, S.BUNNY], args.width, args.height, args, device)
+                # What eight GPUs would each get: the eight row bands of this frame, one after the other on this
+                # GPU, each with a full-size pool as in the N = 8 run.  The slowest band sets the frame time.
+                bands = [quick_rate(files, args.width, args.height, args, device, band=tiling.band_of(r, 8, args.height), steps=24)
+                         for r in range(8)]
+                ms = [b["ms_per_step"] for b in bands]
+                total = sum(b["mrays_per_s"] * b["ms_per_step"] for b in bands) / max(ms)
+                extra["eight_bands_on_one_gpu"] = {
+                    "ms_per_step": ms, "mrays_per_s": [b["mrays_per_s"] for b in bands],
+                    "predicted_8gpu_mrays_per_s": total,
+                    "predicted_scaling_efficiency": total / 8 / out["value"],
+                    "note": "rays of all bands per step of the slowest band, over 8 x the single-GPU rate; excludes the all-gather"}
+            except Exception as e:
+                extra["error"] = str(e)
+            out["extra"] = extra
         if world == 1 and args.cpu_seconds > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, files, args.cpu_seconds)

@@ -97,6 +97,12 @@ const uint32_t *rth_scene_triangles(const rth_scene *s, size_t *count)
 uint32_t rth_scene_pool_size(const rth_scene *s) { return s->scene.pool_size; }
 uint32_t rth_scene_row_offset(const rth_scene *s) { return s->scene.row_offset; }
 uint64_t rth_scene_resident_triangles(const rth_scene *s) { return s->scene.resident_triangles; }
+void rth_scene_timings(const rth_scene *s, double out[3])
+{
+    out[0] = s->scene.ingest_seconds;
+    out[1] = s->scene.build_seconds;
+    out[2] = double(s->scene.models_from_cache);
+}
 
 int rth_write_standin_ply(const char *path, uint32_t around, uint32_t rings)
 {

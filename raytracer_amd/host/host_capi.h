@@ -35,6 +35,9 @@ const uint32_t *rth_scene_triangles(const rth_scene *scene, size_t *count);
 uint32_t rth_scene_pool_size(const rth_scene *scene);
 uint32_t rth_scene_row_offset(const rth_scene *scene);
 uint64_t rth_scene_resident_triangles(const rth_scene *scene);
+/* out[0] = seconds spent reading the model files, out[1] = seconds of hierarchy build and scene assembly,
+ * out[2] = number of model files whose parsed arrays came from the binary cache (Model::load). */
+void rth_scene_timings(const rth_scene *scene, double out[3]);
 
 /* Writes the dragon stand-in mesh as ASCII PLY; 0 on success. */
 int rth_write_standin_ply(const char *path, uint32_t around, uint32_t rings);

@@ -7,6 +7,9 @@
 
 #include "model.h"
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
@@ -147,6 +150,82 @@ bool slurp(const char *file, std::vector<char> &text)
     return got == size_t(size);
 }
 
+// Binary cache of a parsed PLY file: vertex positions and face indices, keyed by a hash of the file's
+// bytes.  Parsing the ASCII text of a large mesh with strtof is the slow part of start-up (the
+// reference's fscanf loop, model.cpp:162-190, is slower still); reading the file and hashing it is
+// not.  The cache lives in $RT_MESH_CACHE, or in rt_mesh_cache_<uid> under $TMPDIR or /tmp; an empty
+// RT_MESH_CACHE switches it off.  A cache file that does not match in every header field is ignored.
+struct CacheHeader {
+    char magic[8];  // "RTMESH1"
+    uint64_t hash, file_size, n_vtx, n_tri;
+};
+
+uint64_t fnv1a(const char *data, size_t size)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < size; i++) {
+        h ^= (unsigned char)data[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+std::string cache_path(const char *file, uint64_t hash)
+{
+    const char *dir = std::getenv("RT_MESH_CACHE");
+    std::string base;
+    if (dir) {
+        if (!*dir) return "";
+        base = dir;
+    } else {
+        const char *tmp = std::getenv("TMPDIR");
+        base = std::string(tmp && *tmp ? tmp : "/tmp") + "/rt_mesh_cache_" + std::to_string((unsigned long)getuid());
+    }
+    ::mkdir(base.c_str(), 0700);
+    std::string name = file;
+    const size_t slash = name.find_last_of('/');
+    if (slash != std::string::npos) name = name.substr(slash + 1);
+    char hex[20];
+    std::snprintf(hex, sizeof(hex), "%016llx", (unsigned long long)hash);
+    return base + "/" + name + "." + hex + ".rtmesh";
+}
+
+bool read_cache(const std::string &path, uint64_t hash, uint64_t file_size, std::vector<Vec3> &positions,
+                std::vector<std::array<uint32_t, 3>> &faces)
+{
+    FILE *in = std::fopen(path.c_str(), "rb");
+    if (!in) return false;
+    CacheHeader h;
+    bool ok = std::fread(&h, sizeof(h), 1, in) == 1 && !std::memcmp(h.magic, "RTMESH1", 8) && h.hash == hash &&
+              h.file_size == file_size && h.n_vtx && h.n_tri && h.n_vtx < (1ull << 32) && h.n_tri < (1ull << 32);
+    if (ok) {
+        positions.resize(h.n_vtx);
+        faces.resize(h.n_tri);
+        ok = std::fread(positions.data(), sizeof(Vec3), h.n_vtx, in) == h.n_vtx &&
+             std::fread(faces.data(), sizeof(faces[0]), h.n_tri, in) == h.n_tri && std::fgetc(in) == EOF;
+    }
+    std::fclose(in);
+    return ok;
+}
+
+void write_cache(const std::string &path, uint64_t hash, uint64_t file_size, const std::vector<Vec3> &positions,
+                 const std::vector<std::array<uint32_t, 3>> &faces)
+{
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *out = std::fopen(tmp.c_str(), "wb");
+    if (!out) return;
+    CacheHeader h;
+    std::memcpy(h.magic, "RTMESH1", 8);
+    h.hash = hash;
+    h.file_size = file_size;
+    h.n_vtx = positions.size();
+    h.n_tri = faces.size();
+    bool ok = std::fwrite(&h, sizeof(h), 1, out) == 1 && std::fwrite(positions.data(), sizeof(Vec3), positions.size(), out) == positions.size() &&
+              std::fwrite(faces.data(), sizeof(faces[0]), faces.size(), out) == faces.size();
+    ok = std::fclose(out) == 0 && ok;
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+}
+
 }  // namespace
 
 bool Model::load(const char *file)
@@ -154,6 +233,18 @@ bool Model::load(const char *file)
     if (!pos_.empty() || !faces_.empty()) return false;
     std::vector<char> text;
     if (!slurp(file, text)) return false;
+    const uint64_t file_size = text.size() - 1, hash = fnv1a(text.data(), file_size);
+    const std::string cached = cache_path(file, hash);
+    if (!cached.empty()) {
+        std::vector<Vec3> positions;
+        std::vector<std::array<uint32_t, 3>> faces;
+        if (read_cache(cached, hash, file_size, positions, faces) && assign(positions, faces)) {
+            from_cache_ = true;
+            return true;
+        }
+        pos_.clear();
+        faces_.clear();
+    }
     Tokens tok(std::move(text));
 
     // Header, in the fixed order the reference's scanf templates demand (model.cpp:145-160).
@@ -198,7 +289,9 @@ bool Model::load(const char *file)
             faces[i][k] = uint32_t(v[k]);
         }
     }
-    return assign(positions, faces);
+    if (!assign(positions, faces)) return false;
+    if (!cached.empty()) write_cache(cached, hash, file_size, positions, faces);
+    return true;
 }
 
 bool Model::assign(const std::vector<Vec3> &positions, const std::vector<std::array<uint32_t, 3>> &faces)

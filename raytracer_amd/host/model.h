@@ -77,6 +77,7 @@ public:
     // Reads an ASCII PLY file of the dialect the reference accepts (model.cpp:143-160): one comment
     // line, float x y z plus up to four more float vertex properties, triangular faces.
     bool load(const char *file);
+    bool loaded_from_cache() const { return from_cache_; }  // load() found the file's parsed arrays in the binary cache
     // Takes a mesh that is already in memory.
     bool assign(const std::vector<Vec3> &positions, const std::vector<std::array<uint32_t, 3>> &faces);
 
@@ -93,6 +94,7 @@ public:
     uint32_t group_id() const { return group_id_; }
 
 private:
+    bool from_cache_ = false;
     struct Face {
         uint32_t v[3];
         Vec3 center;

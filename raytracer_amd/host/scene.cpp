@@ -6,6 +6,7 @@
 
 #include "scene.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,13 +82,20 @@ bool build_scene(const SceneSpec &spec, Scene &scene, std::string &error)
     mngr.reserve_groups(6);  // spawn, sky, light, two materials, scene root (main.cpp:285, 310-313)
     mngr.reserve_aabbs(n_obj);
 
+    const auto seconds_since = [](std::chrono::steady_clock::time_point from) {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - from).count();
+    };
+    const auto build_start = std::chrono::steady_clock::now();
     std::vector<std::unique_ptr<Model>> models;
     for (const std::string &file : spec.model_files) {
         models.emplace_back(new Model);
+        const auto load_start = std::chrono::steady_clock::now();
         if (!models.back()->load(file.c_str())) {
             error = "cannot load model " + file;
             return false;
         }
+        scene.ingest_seconds += seconds_since(load_start);
+        scene.models_from_cache += models.back()->loaded_from_cache() ? 1 : 0;
         try {
             models.back()->subdivide(spec.tri_threshold, spec.aabb_threshold);
             models.back()->reserve(mngr);
@@ -151,6 +159,7 @@ bool build_scene(const SceneSpec &spec, Scene &scene, std::string &error)
     scene.aabbs.swap(mngr.aabbs());
     scene.vertices.swap(mngr.vertices());
     scene.triangles.swap(mngr.triangles());
+    scene.build_seconds = seconds_since(build_start) - scene.ingest_seconds;
     return true;
 }
 

@@ -32,6 +32,9 @@ struct Scene {
     uint32_t pool_size = 0;    // ray slots after alignment (main.cpp:188)
     uint32_t row_offset = 0;   // first row of the band (rt_config.row_offset)
     uint64_t resident_triangles = 0;  // sum over instances of their model's triangle count
+    double ingest_seconds = 0;        // reading the model files (text parse, or the binary cache of Model::load)
+    double build_seconds = 0;         // hierarchy build and scene assembly
+    uint32_t models_from_cache = 0;
 };
 
 inline size_t align_up(size_t value, size_t unit)

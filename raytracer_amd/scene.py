@@ -44,6 +44,7 @@ def host_lib():
         lib.rth_scene_row_offset.argtypes = [C.c_void_p]
         lib.rth_scene_resident_triangles.restype = C.c_uint64
         lib.rth_scene_resident_triangles.argtypes = [C.c_void_p]
+        lib.rth_scene_timings.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.rth_write_standin_ply.restype = C.c_int
         lib.rth_write_standin_ply.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
         lib.rth_set_camera.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float,
@@ -63,6 +64,9 @@ class Scene:
     pool_size: int
     row_offset: int
     resident_triangles: int
+    ingest_seconds: float = 0.0      # reading the model files (text parse, or the host's binary mesh cache)
+    build_seconds: float = 0.0       # hierarchy build + scene assembly
+    models_from_cache: int = 0
 
     @property
     def group_count(self):
@@ -101,7 +105,10 @@ def build_scene(models, width=1024, height=1024, ray_count=1024 * 1024, n_obj=25
             ptr = getattr(lib, "rth_scene_" + name)(handle, C.byref(n))
             return _copy(ptr, n.value, np.dtype(dtype))
 
+        times = (C.c_double * 3)()
+        lib.rth_scene_timings(handle, times)
         return Scene(
+            ingest_seconds=times[0], build_seconds=times[1], models_from_cache=int(times[2]),
             data=_copy(lib.rth_scene_global(handle), 1, L.global_dtype),
             groups=arr("groups", L.group_dtype), matrices=arr("matrices", L.matrix_dtype),
             aabbs=arr("aabbs", L.aabb_dtype), vertices=arr("vertices", L.vertex_dtype),

@@ -108,3 +108,27 @@ def test_band_scene_keeps_full_camera():
 def test_bad_model_path_is_reported():
     with pytest.raises(RuntimeError, match="cannot load model"):
         S.build_scene(["/nonexistent.ply"], 64, 64, 8192)
+
+
+def test_mesh_cache_gives_the_same_scene(tmp_path, monkeypatch):
+    """Model::load keeps the parsed arrays of a PLY file in a binary cache keyed by a hash of the file's
+    bytes: the scene built from the cache is byte-identical, a damaged cache file is ignored."""
+    import glob
+    names = ("groups", "aabbs", "vertices", "triangles", "matrices", "data")
+    monkeypatch.setenv("RT_MESH_CACHE", "")                      # switched off: parse the text
+    plain = S.build_scene([S.BUNNY, S.BUNNY], 64, 64, 8192)
+    assert plain.models_from_cache == 0
+    monkeypatch.setenv("RT_MESH_CACHE", str(tmp_path))
+    first = S.build_scene([S.BUNNY, S.BUNNY], 64, 64, 8192)      # second model file of the list already finds the first's cache
+    files = glob.glob(str(tmp_path / "*.rtmesh"))
+    assert len(files) == 1 and first.models_from_cache == 1
+    again = S.build_scene([S.BUNNY, S.BUNNY], 64, 64, 8192)
+    assert again.models_from_cache == 2
+    for sc in (first, again):
+        for n in names:
+            assert np.ascontiguousarray(getattr(sc, n)).tobytes() == np.ascontiguousarray(getattr(plain, n)).tobytes(), n
+    raw = bytearray(open(files[0], "rb").read())
+    open(files[0], "wb").write(raw[:len(raw) // 2])              # truncated: must be ignored, then rewritten
+    damaged = S.build_scene([S.BUNNY], 64, 64, 8192, n_obj=4)
+    assert damaged.models_from_cache == 0
+    assert os.path.getsize(files[0]) == len(raw)

@@ -32,7 +32,7 @@ def main():
         d = os.path.join(args.out, name)
         cmd = ["timeout", "-s", "KILL", "240", "rocprofv3", "--pmc", *PASSES[name], "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--cpu-seconds", "0", *args.extra.split()]
+               "--cpu-seconds", "0", "--no-extras", *args.extra.split()]
         print("pass", name, flush=True)
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if r.returncode:

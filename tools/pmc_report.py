@@ -6,12 +6,16 @@ import json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+schedule = sys.argv[2] if len(sys.argv) > 2 else "free"   # which bench.py --schedule the counters were collected on
 src = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc_summary.json")))
 report, traffic = {}, {}
 for name, c in sorted(src.items()):
     if "rtd::k_" not in name:
         continue
     k = name.split("::")[-1]
+    if k.endswith("<true>" if schedule == "reference" else "<false>"):
+        continue  # the other schedule's instance of a kernel (not launched in this run, or only by set-up calls)
+    k = k.split("<")[0]
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte read requests as 64 bytes,
     # so the read side is doubled (calibrated for wide streaming reads; other widths are uncalibrated).
     rd = 2 * c.get("FETCH_SIZE", 0.0) * 1024
@@ -38,7 +42,12 @@ for name, c in sorted(src.items()):
     }
     traffic[k] = rd + wr
 json.dump(report, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+import hashlib
+lib = os.path.join(ROOT, "raytracer_amd", "csrc", "librt_hip.so")
+stamp = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "schedule": schedule,
+         "unit": "HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies a 128-byte read request as 64 bytes)",
+         "kernels": traffic}
+json.dump(stamp, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for k, r in report.items():
     print(f"{k:18s} rd {r['hbm_read_bytes']/1e6:7.1f} MB wr {r['hbm_write_bytes']/1e6:7.1f} MB  L2 hit {r['l2_hit_rate']:.2f}  "
           f"VALU util {r['valu_utilisation'] or 0:.2f}  wait {r['share_waiting']:.2f} stall {r['share_issue_stalled']:.2f} issue {r['share_issuing']:.2f}")
