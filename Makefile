@@ -34,9 +34,12 @@ $(CSRC)/librt_hip.so: $(HIP_SOURCES) $(HIP_HEADERS)
 $(HOST)/librt_host.so: $(HOST_LIB_SOURCES) $(HOST_HEADERS)
 	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SOURCES) -o $@
 
-$(HOST)/rt_main: $(HOST)/main.cpp $(HOST)/raytracer.cpp $(HOST)/librt_host.so $(CSRC)/librt_hip.so $(HOST_HEADERS)
-	$(CXX) $(CXXFLAGS) $(HOST)/main.cpp $(HOST)/raytracer.cpp -o $@ \
-	    -L$(HOST) -lrt_host -L$(CSRC) -lrt_hip -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
+ROCM ?= /opt/rocm
+# tiled.cpp holds the multi-GPU gather: HIP runtime API and RCCL from plain C++ (no device code)
+$(HOST)/rt_main: $(HOST)/main.cpp $(HOST)/raytracer.cpp $(HOST)/tiled.cpp $(HOST)/librt_host.so $(CSRC)/librt_hip.so $(HOST_HEADERS)
+	$(CXX) $(CXXFLAGS) -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include $(HOST)/main.cpp $(HOST)/raytracer.cpp $(HOST)/tiled.cpp -o $@ \
+	    -L$(HOST) -lrt_host -L$(CSRC) -lrt_hip -L$(ROCM)/lib -lrccl -lamdhip64 \
+	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc' -Wl,-rpath,$(ROCM)/lib
 
 clean:
 	rm -f $(CSRC)/librt_hip.so $(HOST)/librt_host.so $(HOST)/rt_main

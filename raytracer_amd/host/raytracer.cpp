@@ -54,6 +54,7 @@ bool RayTracer::init(int device)
     cfg.warp_width = warp_width;
     cfg.sample_limit = sample_limit;
     cfg.row_offset = scene_.row_offset;
+    cfg.flags = flags;
     if (!report("Cannot create context", rt_create(&cfg, &ctx_))) return false;
     image_.assign(size_t(cfg.width) * cfg.height * 4, 0);
     return report("Cannot upload scene",
@@ -77,6 +78,23 @@ bool RayTracer::draw_frame()
     return report("Cannot resolve image", rt_resolve_rgba8(ctx_, image_.data(), 0));
 }
 
+bool RayTracer::resolve_to_device(void *device_image)
+{
+    return report("Cannot resolve image", rt_resolve_rgba8(ctx_, device_image, 1));
+}
+
+void *RayTracer::stream()
+{
+    return rt_stream(ctx_);
+}
+
+uint32_t RayTracer::rays_in_flight()
+{
+    rt_global_data g = {};
+    report("Cannot read buffer data", rt_get_global(ctx_, &g));
+    return g.ray_count;
+}
+
 uint32_t RayTracer::current_ray()
 {
     uint32_t value = 0;
@@ -96,13 +114,17 @@ bool RayTracer::set_warp_width(uint32_t w)
 
 bool RayTracer::write_ppm(const char *path) const
 {
+    return write_ppm_file(path, image_.data(), width_, height());
+}
+
+bool write_ppm_file(const char *path, const uint8_t *rgba, size_t w, size_t h)
+{
     FILE *out = std::fopen(path, "wb");
     if (!out) return false;
-    const size_t w = width_, h = height();
     std::fprintf(out, "P6\n%zu %zu\n255\n", w, h);
     std::vector<uint8_t> row(w * 3);
     for (size_t y = h; y-- > 0;) {
-        const uint8_t *src = image_.data() + y * w * 4;
+        const uint8_t *src = rgba + y * w * 4;
         for (size_t x = 0; x < w; x++) {
             row[3 * x + 0] = src[4 * x + 0];
             row[3 * x + 1] = src[4 * x + 1];

@@ -28,6 +28,7 @@ public:
     uint32_t warp_width = 64;            // queue-compaction granularity (the reference: 32)
     uint32_t band_first = 0, band_rows = 0;  // row band of this GPU; 0 rows = whole frame
     uint32_t sample_limit = 0;
+    uint32_t flags = 0;                  // rt_config.flags: RT_FLAG_FREE_SCHEDULE, RT_FLAG_SHADING(...)
 
     // Builds the scene on the host, creates the device context and uploads (main.cpp:192-195).
     bool init(int device);
@@ -35,6 +36,10 @@ public:
     bool make_step();
     // Resolves the accumulator to RGBA8 (main.cpp:479-490); the image is kept in image().
     bool draw_frame();
+    // The same resolve into a device buffer of width * height() * 4 bytes on this context's GPU; no host copy.
+    bool resolve_to_device(void *device_image);
+    void *stream();                      // the context's hipStream_t
+    uint32_t rays_in_flight();           // GlobalData.ray_count
     uint32_t current_ray();
     bool counters(rt_counters &out);
     bool set_warp_width(uint32_t w);
@@ -56,5 +61,8 @@ private:
     Scene scene_;
     std::vector<uint8_t> image_;
 };
+
+// RGBA8 rows (first row first) as a binary PPM, first row at the bottom as the reference's GL quad shows it.
+bool write_ppm_file(const char *path, const uint8_t *rgba, size_t width, size_t height);
 
 }  // namespace rt

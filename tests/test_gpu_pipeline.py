@@ -376,7 +376,7 @@ def test_cpp_host_renders_the_same_frame(tmp_path, bunny_scene_128):
     assert os.path.exists(exe), "run `make host` (or __graft_entry__.build())"
     out = str(tmp_path / "frame.ppm")
     run = subprocess.run([exe, "--width", "128", "--height", "128", "--rays", "16384", "--frames", "1", "--steps", "32",
-                          "--warp", "32", "--models", S.BUNNY + ";" + S.BUNNY, "--out", out],
+                          "--warp", "32", "--schedule", "reference", "--models", S.BUNNY + ";" + S.BUNNY, "--out", out],
                          cwd=root, capture_output=True, text=True, timeout=240)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "Frame ready in" in run.stdout
@@ -393,3 +393,41 @@ def test_cpp_host_renders_the_same_frame(tmp_path, bunny_scene_128):
     assert (w, h) == (128, 128)
     # the PPM is written bottom row first (the reference displays its texture with y up)
     assert np.abs(ppm.astype(int) - image[::-1, :, :3].astype(int)).max() <= 1
+
+
+def _read_ppm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = map(int, f.readline().split())
+        assert f.readline().strip() == b"255"
+        return np.frombuffer(f.read(), np.uint8).reshape(h, w, 3)[::-1]   # stored bottom row first
+
+
+def test_cpp_host_tiles_the_frame(tmp_path):
+    """rt_main's multi-GPU path on the one GPU of the box: one sample per pixel, run until no ray is in flight.
+    (a) two bands rendered alone, as two ranks would, assemble to the single-context frame; (b) two bands
+    in one process (--devices 0,0: two contexts, gathered by device copies) give the same frame; (c) so does the
+    RCCL all-gather with a single rank (--rccl), which is the gather --gpus N uses on N distinct devices."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracer_amd", "host", "rt_main")
+    base = [exe, "--width", "128", "--height", "96", "--spp", "1", "--steps", "12", "--models", S.BUNNY + ";" + S.BUNNY]
+
+    def run(extra, name):
+        out = str(tmp_path / name)
+        r = subprocess.run(base + extra + ["--out", out], cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "still in flight" not in r.stdout
+        return _read_ppm(out), r.stdout
+
+    full, _ = run([], "full.ppm")
+    assert full.shape == (96, 128, 3) and full.max() > 100
+    top, _ = run(["--band-first", "0", "--band-rows", "40"], "top.ppm")
+    bottom, _ = run(["--band-first", "40", "--band-rows", "56"], "bottom.ppm")
+    assert np.abs(np.concatenate([top, bottom]).astype(int) - full.astype(int)).max() <= 1
+    both, log = run(["--devices", "0,0"], "both.ppm")
+    assert "2 band(s), gathered by device copies" in log
+    assert np.abs(both.astype(int) - full.astype(int)).max() <= 1
+    one, log = run(["--rccl"], "rccl.ppm")
+    assert "1 band(s), gathered with RCCL" in log
+    assert np.abs(one.astype(int) - full.astype(int)).max() <= 1
