@@ -8,13 +8,13 @@ dragon = os.path.join(tempfile.gettempdir(), "rt_dragon_standin_tool.ply")
 if not os.path.exists(dragon):
     S.write_standin_ply(dragon)
 files = [S.BUNNY, dragon]
-for parts in (1, 2, 3, 4):
+for parts in (1, 2, 3):
     rts = []
     for r in range(parts):
         first, rows = tiling.band_of(r, parts, H)
         pool = S.L.align_up(W * H // parts, S.L.SORT_TILE)
         sc = S.build_scene(files, W, H, pool, band_first=first, band_rows=rows)
-        rt = api.RayTracer(sc, warp_width=64)
+        rt = api.RayTracer(sc, warp_width=64, free_schedule=True)
         rt.init_frame()
         rts.append(rt)
     for k in range(96):
