@@ -48,7 +48,7 @@ clean:
 .PHONY: all device host oracle clean stamps variant resources
 
 # Diagnostic build with per-phase cycle stamps in the kernels (never loaded by default; RT_HIP_LIB selects it).
-stamps: $(CSRC)/librt_hip_stamps1.so $(CSRC)/librt_hip_stamps2.so $(CSRC)/librt_hip_stamps3.so
+stamps: $(CSRC)/librt_hip_stamps1.so $(CSRC)/librt_hip_stamps2.so $(CSRC)/librt_hip_stamps3.so $(CSRC)/librt_hip_stamps4.so
 $(CSRC)/librt_hip_stamps%.so: $(HIP_SOURCES) $(HIP_HEADERS)
 	$(HIPCC) $(HIPFLAGS) -DRT_STAMPS=$* $(HIP_SOURCES) -o $@
 

@@ -31,6 +31,14 @@ namespace rtd {
 #define AABB_STAMP(v)
 #define AABB_STAMP_ADD(f, s, a, b)
 #endif
+// =4: inside the merge of the box kernel: child ids landed, pending entries landed, ranks and stores issued, whole visit
+#if defined(RT_STAMPS) && RT_STAMPS == 4
+#define MERGE_STAMP(v) RT_STAMP(v)
+#define MERGE_STAMP_ADD(f, s, a, b) RT_STAMP_ADD(f, s, a, b)
+#else
+#define MERGE_STAMP(v)
+#define MERGE_STAMP_ADD(f, s, a, b)
+#endif
 #if defined(RT_STAMPS) && RT_STAMPS == 2
 #define MISC_STAMP(v) RT_STAMP(v)
 #define MISC_STAMP_ADD(f, s, a, b) RT_STAMP_ADD(f, s, a, b)
@@ -631,6 +639,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
                                            uint32_t tid, uint32_t &new_key, uint32_t &group_flags)
 {
     AABB_STAMP(t_start);
+    MERGE_STAMP(t_m_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
     const uint32_t count = grp.y;
     group_flags = grp.z;
@@ -841,6 +850,13 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
             cand_local[j] = list[bi].local_id;
         }
     }
+#if defined(RT_STAMPS) && RT_STAMPS == 4
+    MERGE_STAMP(t_m0);
+    asm volatile("" ::"v"(cand_group[0]), "v"(cand_group[1]), "v"(cand_group[2]), "v"(cand_group[3]), "v"(cand_local[0]), "v"(cand_local[3]), "v"(cand_group[7]), "v"(cand_local[7]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MERGE_STAMP(t_m1);
+    MERGE_STAMP_ADD(a.frame, 0, t_m0, t_m1);
+#endif
     const uint32_t merged = old_len - 1 + n;
     const bool overflow = merged >= RT_MAX_QUEUE_LEN;
     const uint32_t k = overflow ? RT_MAX_QUEUE_LEN : merged;
@@ -861,23 +877,50 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         asm volatile("" ::"v"(e.pos), "v"(e.group_id), "v"(e.local0), "v"(e.local1), "v"(at));
 #endif
     };
+    // The counts run over 7 x 8 pairs in full; most visits have few pending entries and few candidates, so the
+    // loops are cut, wave-uniformly, at the largest numbers any lane of the wave has (in halves of four).
+    const bool many_old = __ballot(old_len > 4) != 0, many_new = __ballot(n > 4) != 0;
+    const bool some_old = __ballot(old_len > 1) != 0;
+    auto candidates_before = [&](float pos) {  // candidates strictly before a pending entry
+        uint32_t c = 0;
 #pragma unroll
-    for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
-        if ((uint32_t)i < old_len) {
-            uint32_t at = i - 1;
+        for (int j = 0; j < 4; j++) c += cand_pos[j] < pos ? 1u : 0u;
+        if (many_new) {
 #pragma unroll
-            for (int j = 0; j < RT_MAX_QUEUE_LEN; j++) at += cand_pos[j] < q[i].pos ? 1u : 0u;
-            place(at, q[i]);
+            for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) c += cand_pos[j] < pos ? 1u : 0u;
+        }
+        return c;
+    };
+    auto pending_not_after = [&](float pos) {  // pending entries a candidate goes behind
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 1; i < 4; i++) c += ((uint32_t)i < old_len && !(pos < q[i].pos)) ? 1u : 0u;
+        if (many_old) {
+#pragma unroll
+            for (int i = 4; i < RT_MAX_QUEUE_LEN; i++) c += ((uint32_t)i < old_len && !(pos < q[i].pos)) ? 1u : 0u;
+        }
+        return c;
+    };
+    if (some_old) {
+#pragma unroll
+        for (int i = 1; i < 4; i++)
+            if ((uint32_t)i < old_len) place(i - 1 + candidates_before(q[i].pos), q[i]);
+        if (many_old) {
+#pragma unroll
+            for (int i = 4; i < RT_MAX_QUEUE_LEN; i++)
+                if ((uint32_t)i < old_len) place(i - 1 + candidates_before(q[i].pos), q[i]);
         }
     }
+    auto place_candidate = [&](int j) {
+        if ((uint32_t)j < n)
+            place(j + (some_old ? pending_not_after(cand_pos[j]) : 0u),
+                  RayHit{cand_pos[j], cand_group[j], take0 ? cand_local[j] : head.local0, take1 ? cand_local[j] : head.local1});
+    };
 #pragma unroll
-    for (int j = 0; j < RT_MAX_QUEUE_LEN; j++) {
-        if ((uint32_t)j < n) {
-            uint32_t at = j;
+    for (int j = 0; j < 4; j++) place_candidate(j);
+    if (many_new) {
 #pragma unroll
-            for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) at += ((uint32_t)i < old_len && !(cand_pos[j] < q[i].pos)) ? 1u : 0u;
-            place(at, RayHit{cand_pos[j], cand_group[j], take0 ? cand_local[j] : head.local0, take1 ? cand_local[j] : head.local1});
-        }
+        for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) place_candidate(j);
     }
     // save_queue (ray-tracer.cl:157-165)
     if (k) {
@@ -893,6 +936,14 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     }
     AABB_STAMP(t_merged);
     AABB_STAMP_ADD(a.frame, 3, t_sorted, t_merged);
+#if defined(RT_STAMPS) && RT_STAMPS == 4
+    MERGE_STAMP(t_m2);
+    MERGE_STAMP_ADD(a.frame, 1, t_m1, t_m2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MERGE_STAMP(t_m3);
+    MERGE_STAMP_ADD(a.frame, 2, t_m2, t_m3);
+    MERGE_STAMP_ADD(a.frame, 3, t_m_start, t_m3);
+#endif
     return true;
 }
 
