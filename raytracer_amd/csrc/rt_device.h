@@ -23,19 +23,21 @@ struct RayHit {
     uint32_t local0, local1;
 };
 
-// One ray slot, 256 bytes, 256-byte aligned: the fields every traversal step touches (meta, ray,
-// head of the queue) sit in the first 128-byte line.  Same content as the reference's RayQueue
-// (ray-tracer.h:164-170) plus the sample id and the triangle of the last committed hit.
+// One ray slot, 256 bytes, 256-byte aligned.  Same content as the reference's RayQueue
+// (ray-tracer.h:164-170) plus the sample id.  The first 64 bytes are what every visit reads (three
+// 16-byte loads for the ray, one for the head of the queue); the fields a visit changes lie next to each
+// other so that one store covers them: (queue_len, t_min) after a visit, (material_id, queue_len, t_min,
+// t_max) after a hit.  The kernels are bound by the number of store requests, not by their bytes.
 struct alignas(256) RaySlot {
     uint32_t pixel, type, material_id, queue_len;  //   0
-    float4 start_min;                              //  16  (start.xyz, t_min)
-    float4 dir_max;                                //  32  (dir.xyz, t_max)
+    float t_min, t_max;                            //  16
+    float start[3], dir[3];                        //  24, 36
     RayHit queue[RT_MAX_QUEUE_LEN];                //  48
     float4 weight;                                 // 176
     float4 norm;                                   // 192
     RayHit orig;                                   // 208
     RayHit root;                                   // 224
-    uint32_t sample_id, hit_tri, pad0, pad1;       // 240
+    uint32_t sample_id, pad0, pad1, pad2;          // 240
 };
 static_assert(sizeof(RaySlot) == 256, "ray slot must be 256 bytes");
 
@@ -133,6 +135,38 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b)
 {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+// The fields of a slot every visit reads, in registers: bytes 0-47 of the slot, three 16-byte requests.
+struct HotRay {
+    uint32_t pixel, type, material_id, queue_len;
+    float t_min, t_max;
+    V3 start, dir;
+};
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ HotRay load_hot(const RaySlot *ray)
+{
+    const uint4 a = *reinterpret_cast<const uint4 *>(ray);
+    const float4 b = *reinterpret_cast<const float4 *>(&ray->t_min), c = *reinterpret_cast<const float4 *>(&ray->start[2]);
+    return HotRay{a.x, a.y, a.z, a.w, b.x, b.y, V3{b.z, b.w, c.x}, V3{c.y, c.z, c.w}};
+}
+__device__ __forceinline__ void store_hot(RaySlot *ray, const HotRay &h)
+{
+    *reinterpret_cast<uint4 *>(ray) = make_uint4(h.pixel, h.type, h.material_id, h.queue_len);
+    *reinterpret_cast<float4 *>(&ray->t_min) = make_float4(h.t_min, h.t_max, h.start.x, h.start.y);
+    *reinterpret_cast<float4 *>(&ray->start[2]) = make_float4(h.start.z, h.dir.x, h.dir.y, h.dir.z);
+}
+// queue_len and t_min, one 8-byte request (save_queue, ray-tracer.cl:157-165)
+__device__ __forceinline__ void store_progress(RaySlot *ray, uint32_t queue_len, float t_min)
+{
+    *reinterpret_cast<u32x2_a4 *>(&ray->queue_len) = u32x2_a4{queue_len, __float_as_uint(t_min)};
+}
+// material_id, queue_len, t_min and t_max, one 16-byte request (insert_stop, ray-tracer.cl:173-203)
+__device__ __forceinline__ void store_commit(RaySlot *ray, uint32_t material_id, uint32_t queue_len, float t_min, float t_max)
+{
+    *reinterpret_cast<u32x4_a4 *>(&ray->material_id) = u32x4_a4{material_id, queue_len, __float_as_uint(t_min), __float_as_uint(t_max)};
+}
+
 __device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
 
 __device__ __forceinline__ float pow5(float x)

@@ -73,23 +73,32 @@ __device__ __forceinline__ float subpixel(uint32_t val)
     return ((float)val - 0.5f) / 15.0f;
 }
 
-// reset_ray (ray-tracer.cl:10-16)
-__device__ __forceinline__ uint32_t reset_ray(RaySlot *ray, uint32_t group_id, uint32_t local0, uint32_t local1,
+// reset_ray (ray-tracer.cl:10-16) for a ray whose hot fields are in registers: the first 64 bytes of the
+// slot go out as four 16-byte requests.  LEAN (the free schedule's kernels): `orig` is not kept up -- no
+// kernel reads it, the hit record holds what was hit.
+template <bool LEAN>
+__device__ __forceinline__ uint32_t reset_ray(RaySlot *ray, HotRay h, uint32_t group_id, uint32_t local0, uint32_t local1,
                                               uint32_t end_group)
 {
-    ray->orig.group_id = group_id;
-    ray->orig.local0 = local0;
-    ray->orig.local1 = local1;
+    h.t_min = 0.001f;
+    h.t_max = INFINITY;
+    h.queue_len = 1;
+    h.material_id = end_group;
+    store_hot(ray, h);
     ray->queue[0] = RayHit{0.001f, group_id, local0, local1};
-    ray->start_min.w = 0.001f;
-    ray->dir_max.w = INFINITY;
-    ray->queue_len = 1;
-    ray->material_id = end_group;
+    if (!LEAN) {
+        ray->orig.group_id = group_id;
+        ray->orig.local0 = local0;
+        ray->orig.local1 = local1;
+    }
     return group_id;
 }
 
 // init_ray (ray-tracer.cl:56-74).  Sample ids at or beyond the limit take the dead-ray exit the
 // reference left commented out (ray-tracer.cl:61): the slot is left alone and parked in the last group.
+// LEAN: `root` is not stored again -- every slot of the pool got the camera's root when the frame was
+// initialised, and nothing else ever writes it.
+template <bool LEAN>
 __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlobal *glob, RaySlot *ray,
                                              rt_hit_record *hits, uint32_t group_count, uint32_t sample, bool &started)
 {
@@ -103,22 +112,18 @@ __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlob
     const float x = (float)(pixel % cam.width) + subpixel(sx);
     const float y = (float)(pixel / cam.width + glob->row_offset) + subpixel(sy);
 
-    ray->pixel = pixel;
-    ray->type = RT_RAY_PRIMARY;
-    ray->weight = make_float4(1, 1, 1, 1);
     const V3 tl = v3(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
     const V3 dx = v3(cam.dx[0], cam.dx[1], cam.dx[2]), dy = v3(cam.dy[0], cam.dy[1], cam.dy[2]);
-    const V3 dir = normalize((tl + dx * x) + dy * y);
-    ray->start_min.x = cam.eye[0];
-    ray->start_min.y = cam.eye[1];
-    ray->start_min.z = cam.eye[2];
-    ray->dir_max.x = dir.x;
-    ray->dir_max.y = dir.y;
-    ray->dir_max.z = dir.z;
-    ray->root = RayHit{0.0f, cam.root_group, cam.root_local, 0u};
+    HotRay h;
+    h.pixel = pixel;
+    h.type = RT_RAY_PRIMARY;
+    h.start = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
+    h.dir = normalize((tl + dx * x) + dy * y);
+    ray->weight = make_float4(1, 1, 1, 1);
+    if (!LEAN) ray->root = RayHit{0.0f, cam.root_group, cam.root_local, 0u};
     ray->sample_id = sample;
     if (sample < glob->hit_capacity) hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    return reset_ray(ray, cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
+    return reset_ray<LEAN>(ray, h, cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
 }
 
 // One atomic per wave for a per-lane event count (each counted lane adds `weight`, wave-uniform), to
@@ -147,7 +152,7 @@ __global__ void k_init_rays(ProcessArgs a, uint32_t pool)
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= pool) return;
     bool started;
-    const uint32_t key = init_ray(a.cam, a.frame.glob, &a.frame.rays[index], a.frame.hits, a.group_count, index, started);
+    const uint32_t key = init_ray<false>(a.cam, a.frame.glob, &a.frame.rays[index], a.frame.hits, a.group_count, index, started);
     a.frame.index[index] = rt_index_pair{key, index};
     count_lanes(a.frame, kPrimarySpawned, started);
     if (index) return;
@@ -166,10 +171,15 @@ __global__ void k_load_rays(ProcessArgs a, uint32_t pool, const rt_ray *rays, ui
     if (index < n_rays) {
         bool started;
         RaySlot *ray = &a.frame.rays[index];
-        key = init_ray(a.cam, a.frame.glob, ray, a.frame.hits, a.group_count, index, started);
+        key = init_ray<false>(a.cam, a.frame.glob, ray, a.frame.hits, a.group_count, index, started);
         const rt_ray r = rays[index];
-        ray->start_min = make_float4(r.start_min[0], r.start_min[1], r.start_min[2], r.start_min[3]);
-        ray->dir_max = make_float4(r.dir_max[0], r.dir_max[1], r.dir_max[2], r.dir_max[3]);
+        asm volatile("" ::: "memory");  // the caller's ray goes over what init_ray has stored
+        ray->t_min = r.start_min[3];
+        ray->t_max = r.dir_max[3];
+        for (int k = 0; k < 3; k++) {
+            ray->start[k] = r.start_min[k];
+            ray->dir[k] = r.dir_max[k];
+        }
         ray->queue[0].pos = r.start_min[3];
     }
     a.frame.index[index] = rt_index_pair{key, index};
@@ -207,14 +217,13 @@ struct LocalRay {
     V3 m0, m1, m2;  // columns of the instance rotation (identity for world-space groups)
 };
 
-__device__ __forceinline__ LocalRay make_local(uint32_t g, const float4 sm, const float4 dm, uint32_t local0,
-                                               const rt_matrix *mat_list)
+__device__ __forceinline__ LocalRay make_local(uint32_t g, const HotRay &h, uint32_t local0, const rt_matrix *mat_list)
 {
     LocalRay r;
-    r.start = xyz(sm);
-    r.dir = xyz(dm);
-    r.tmin = sm.w;
-    r.tmax = dm.w;
+    r.start = h.start;
+    r.dir = h.dir;
+    r.tmin = h.t_min;
+    r.tmax = h.t_max;
     r.m0 = v3(1, 0, 0);
     r.m1 = v3(0, 1, 0);
     r.m2 = v3(0, 0, 1);
@@ -258,8 +267,7 @@ __device__ __forceinline__ uint32_t store_shifted(RaySlot *ray, const OldQueue &
     for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
         if ((uint32_t)i < len) ray->queue[i] = old.e[i + 1];
     if (len) {
-        ray->queue_len = len;
-        ray->start_min.w = head_pos;
+        store_progress(ray, len, head_pos);
         return old.e[1].group_id;
     }
     // Empty: the head becomes the ray's end group.  queue[0].pos keeps its value (the reference leaves
@@ -281,22 +289,25 @@ __device__ __forceinline__ void area_add(float4 *area, uint32_t pixel, float r, 
     unsafeAtomicAdd(px + 3, w);
 }
 
+// LEAN (free schedule): the slot of a finished sample is not marked; its key says it all and the next
+// sample overwrites the queue.
+template <bool LEAN>
 __device__ __forceinline__ uint32_t sky_or_light_shader(const ProcessArgs &a, RaySlot *ray, bool is_light)
 {
     const float4 w = ray->weight;
     const float cr = is_light ? 1.0f : 0.5f;
     area_add(a.frame.area, ray->pixel, w.x * cr, w.y * 1.0f, w.z * 1.0f, w.w * 1.0f);
-    ray->queue[0].group_id = RT_SPAWN_GROUP;
+    if (!LEAN) ray->queue[0].group_id = RT_SPAWN_GROUP;
     return RT_SPAWN_GROUP;
 }
 
 // A sample that bounces instead of being shaded (RT_SHADE_MIRROR: shader.cl:37-39; RT_SHADE_DIFFUSE: a
 // cosine-weighted direction, the normal plus a uniform point of the unit sphere, drawn by Marsaglia's
 // rejection method from hashed counters so that it only depends on seed, sample and bounce number).
-__device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, float4 color, uint32_t shading, uint32_t depth)
+template <bool LEAN>
+__device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, HotRay h, float4 color, uint32_t shading, uint32_t depth)
 {
-    const float4 sm = ray->start_min, dm = ray->dir_max;
-    const V3 dir = xyz(dm), norm = normalize(xyz(ray->norm));
+    const V3 dir = h.dir, norm = normalize(xyz(ray->norm));
     V3 out;
     if ((shading & 15u) == RT_SHADE_MIRROR) {
         out = dir - norm * (2 * dot(dir, norm));
@@ -322,29 +333,25 @@ __device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, float4 color, ui
         w.z *= color.z;
         ray->weight = w;
     }
-    ray->type = RT_RAY_PRIMARY | (depth + 1) << 8;
-    const V3 s0 = xyz(sm) + dir * dm.w;
-    ray->start_min.x = s0.x;
-    ray->start_min.y = s0.y;
-    ray->start_min.z = s0.z;
-    ray->dir_max.x = out.x;
-    ray->dir_max.y = out.y;
-    ray->dir_max.z = out.z;
+    h.type = RT_RAY_PRIMARY | (depth + 1) << 8;
+    h.start = h.start + dir * h.t_max;
+    h.dir = out;
     const RayHit root = ray->root;
-    return reset_ray(ray, root.group_id, root.local0, root.local1, RT_SKY_GROUP);
+    return reset_ray<LEAN>(ray, h, root.group_id, root.local0, root.local1, RT_SKY_GROUP);
 }
 
+template <bool LEAN>
 __device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color, uint32_t shading)
 {
+    HotRay h = load_hot(ray);
     if (shading & 15u) {
-        const uint32_t depth = ray->type >> 8;
-        if (depth < ((shading >> 4) & 15u)) return bounce_shader(ray, color, shading, depth);
+        const uint32_t depth = h.type >> 8;
+        if (depth < ((shading >> 4) & 15u)) return bounce_shader<LEAN>(ray, h, color, shading, depth);
     }
     const float l = 0.57735026f;
     const V3 light = v3(l, -l, l);
     const float alpha = 100, f0 = 0.04f;
-    const float4 sm = ray->start_min, dm = ray->dir_max;
-    const V3 dir = xyz(dm), norm = normalize(xyz(ray->norm));
+    const V3 dir = h.dir, norm = normalize(xyz(ray->norm));
     const V3 hvec = normalize(light - dir);
     float spec = (alpha + 2) / 8 * pow100(fmaxf(0.0f, dot(norm, hvec)));
     spec *= f0 + (1 - f0) * pow5(fmaxf(0.0f, -dot(dir, hvec)));
@@ -358,16 +365,11 @@ __device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color, uint3
     w.z *= c.z;
     w.w *= 1.0f;
     ray->weight = w;
-    ray->type = RT_RAY_SHADOW;
-    const V3 s = xyz(sm) + dir * dm.w;
-    ray->start_min.x = s.x;
-    ray->start_min.y = s.y;
-    ray->start_min.z = s.z;
-    ray->dir_max.x = light.x;
-    ray->dir_max.y = light.y;
-    ray->dir_max.z = light.z;
+    h.type = RT_RAY_SHADOW;
+    h.start = h.start + dir * h.t_max;
+    h.dir = light;
     const RayHit root = ray->root;
-    return reset_ray(ray, root.group_id, root.local0, root.local1, RT_LIGHT_GROUP);
+    return reset_ray<LEAN>(ray, h, root.group_id, root.local0, root.local1, RT_LIGHT_GROUP);
 }
 
 // Free schedule: a ray whose queue has emptied goes to its end group (sky, light, material or spawn).  The
@@ -379,29 +381,27 @@ __device__ __forceinline__ uint32_t run_end_group(uint32_t key, RaySlot *ray, co
     const uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
     if (shader == RT_SH_SPAWN || shader >= RT_SH_AABB) return key;
     asm volatile("" ::: "memory");  // the shader reads what the visit has just stored to the slot
-    if (a.frame.glob->mode & kModeTraceOnly) {
-        const uint32_t dead = a.group_count - 1;
-        ray->queue[0].group_id = dead;
-        return dead;
-    }
-    if (shader != RT_SH_MATERIAL) return sky_or_light_shader(a, ray, shader == RT_SH_LIGHT);
+    if (a.frame.glob->mode & kModeTraceOnly) return a.group_count - 1;
+    if (shader != RT_SH_MATERIAL) return sky_or_light_shader<true>(a, ray, shader == RT_SH_LIGHT);
     const float4 color = *reinterpret_cast<const float4 *>(a.scene.grp + (key & kIdMask));
     count_lanes(a.frame, kShadowSpawned, true);
-    return mat_shader(ray, color, a.frame.glob->shading);
+    return mat_shader<true>(ray, color, a.frame.glob->shading);
 }
 
 // ---------------------------------------------------------------- leaf visit (shader.cl:115-139, ray-tracer.cl:149-203)
 
+// LEAN (free schedule): `orig` is not kept up, and a ray whose queue has emptied is not given its end group
+// as head -- the caller runs that group's shader right away.
+template <bool LEAN>
 __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const ProcessArgs &a)
 {
     MISC_STAMP(t_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // vtx_offs, tri_offs, tri_count, material_id
-    // What the scan needs from the slot (meta, ray, head of the queue) is requested at once.
-    const uint4 meta = *reinterpret_cast<const uint4 *>(ray);  // pixel, type, material_id, queue_len
-    const float4 sm = ray->start_min, dm = ray->dir_max;
-    const uint32_t queue_len = meta.w;
+    // What the scan needs from the slot (its first 64 bytes: ray and head of the queue) is requested at once.
+    const HotRay h = load_hot(ray);
+    const uint32_t queue_len = h.queue_len;
     const RayHit head = ray->queue[0];
-    const LocalRay lr = make_local(g, sm, dm, head.local0, a.scene.mat);
+    const LocalRay lr = make_local(g, h, head.local0, a.scene.mat);
 
     count_lanes(a.frame, kTriTests, true, grp.z);
     // Triangle scan.  Leaf payload is wave-uniform: 48 bytes per triangle (r0, p, q, n) through the
@@ -465,8 +465,8 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
         q[i] = RayHit{0.0f, 0u, 0u, 0u};
         if ((uint32_t)i < queue_len) q[i] = ray->queue[i];
     }
-    const bool hit = hit_index != 0xFFFFFFFFu, shadow = (meta.y & 0xFFu) == RT_RAY_SHADOW;  // (bounce count above the low byte)
-    uint32_t len = queue_len - 1, end_group = meta.z, sid = 0xFFFFFFFFu;
+    const bool hit = hit_index != 0xFFFFFFFFu, shadow = (h.type & 0xFFu) == RT_RAY_SHADOW;  // (bounce count above the low byte)
+    uint32_t len = queue_len - 1, end_group = h.material_id, sid = 0xFFFFFFFFu;
     float shadow_weight = 0;
     V3 nw = v3(0, 0, 0);
     if (hit) {
@@ -490,33 +490,35 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
             if ((uint32_t)i < len && q[i + 1].pos >= best) len = i;
     }
 
+    // save_queue + copy_queue (ray-tracer.cl:157-168, 195-203).  An emptied queue leaves queue_len and t_min
+    // alone; with a hit, the end group and the new t_max go out in the same request as those two.
+    const uint32_t new_len = len ? len : queue_len;
+    const float new_min = len ? head.pos : h.t_min;
     if (hit) {
         if (shadow) {
-            unsafeAtomicAdd(reinterpret_cast<float *>(&a.frame.area[meta.x]) + 3, shadow_weight);
+            unsafeAtomicAdd(reinterpret_cast<float *>(&a.frame.area[h.pixel]) + 3, shadow_weight);
+            store_commit(ray, end_group, new_len, new_min, h.t_max);
         } else {
             ray->norm = make_float4(nw.x, nw.y, nw.z, 0.0f);
-            ray->dir_max.w = best;
-            ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
-            ray->hit_tri = hit_index;
+            if (!LEAN) ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
             // the record is the camera ray's hit: a sample that has bounced keeps it
-            if (meta.y == RT_RAY_PRIMARY && sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
+            if (h.type == RT_RAY_PRIMARY && sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
+            store_commit(ray, end_group, new_len, new_min, best);
         }
-        ray->material_id = end_group;
+    } else if (len) {
+        store_progress(ray, len, head.pos);
     }
-    // save_queue + copy_queue (ray-tracer.cl:157-168, 195-203)
 #pragma unroll
     for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
         if ((uint32_t)i < len) ray->queue[i] = q[i + 1];
-    if (len) {
-        ray->queue_len = len;
-        ray->start_min.w = head.pos;
-        return q[1].group_id;
-    }
+    if (len) return q[1].group_id;
     // Empty: the head becomes the ray's end group; queue[0].pos keeps its value (the reference leaves
-    // it indeterminate, ray-tracer.cl:164,201), queue_len and t_min are left alone.
-    ray->queue[0].group_id = end_group;
-    ray->queue[0].local0 = 0;
-    ray->queue[0].local1 = 0;
+    // it indeterminate, ray-tracer.cl:164,201).
+    if (!LEAN) {
+        ray->queue[0].group_id = end_group;
+        ray->queue[0].local0 = 0;
+        ray->queue[0].local1 = 0;
+    }
     return end_group;
 }
 
@@ -633,7 +635,7 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
 // caller hands every lane that ray's group and slot): the scan and the candidate sort are done by
 // wave_visit_one in the wave's lists c_pos/c_idx with the reference's limit of 64 candidates, and
 // only the lane `owner` merges and stores.
-template <int CAP, int THREADS, bool COOP>
+template <int CAP, int THREADS, bool COOP, bool LEAN>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
                                            uint8_t (*s_idx)[THREADS], float *c_pos, uint16_t *c_idx, uint32_t owner,
                                            uint32_t tid, uint32_t &new_key, uint32_t &group_flags)
@@ -643,13 +645,12 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // aabb_offs, aabb_count, flags
     const uint32_t count = grp.y;
     group_flags = grp.z;
-    // What the scan needs from the slot (meta, ray, head of the queue: its first 64 bytes) is requested
+    // What the scan needs from the slot (ray and head of the queue: its first 64 bytes) is requested
     // now.  No load is issued once the stores of the merge begin.
-    const uint4 meta = *reinterpret_cast<const uint4 *>(ray);  // pixel, type, material_id, queue_len
-    const float4 sm = ray->start_min, dm = ray->dir_max;
-    const uint32_t old_len = meta.w;
+    const HotRay h = load_hot(ray);
+    const uint32_t old_len = h.queue_len;
     const RayHit head = ray->queue[0];
-    const LocalRay lr = make_local(g, sm, dm, head.local0, a.scene.mat);
+    const LocalRay lr = make_local(g, h, head.local0, a.scene.mat);
     const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
     if (!COOP) count_lanes(a.frame, kBoxTests, true, count);  // a redone visit was counted the first time
 
@@ -924,14 +925,15 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     }
     // save_queue (ray-tracer.cl:157-165)
     if (k) {
-        ray->queue_len = k;
-        ray->start_min.w = head.pos;
+        store_progress(ray, k, head.pos);
         new_key = first_group;
     } else {
-        const uint32_t end_group = meta.z;
-        ray->queue[0].group_id = end_group;
-        ray->queue[0].local0 = 0;
-        ray->queue[0].local1 = 0;
+        const uint32_t end_group = h.material_id;
+        if (!LEAN) {
+            ray->queue[0].group_id = end_group;
+            ray->queue[0].local0 = 0;
+            ray->queue[0].local1 = 0;
+        }
         new_key = end_group;
     }
     AABB_STAMP(t_merged);
@@ -982,7 +984,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
     if (FREE) {
         if (key == RT_SPAWN_GROUP) {  // a finished slot: the next sample starts here and visits the root below
             bool started;
-            key = init_ray(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
+            key = init_ray<true>(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
             count_lanes(a.frame, kPrimarySpawned, started);
             asm volatile("" ::: "memory");  // the visit reads the slot init_ray has just written
             shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
@@ -1004,7 +1006,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
             if (key != __builtin_amdgcn_readfirstlane(key)) continue;
             todo = false;
             const uint32_t g = uniform_value(key);  // every lane still here holds the same key
-            done = visit_aabb<kAabbCap, kAabbThreads, false>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key, group_flags);
+            done = visit_aabb<kAabbCap, kAabbThreads, false, FREE>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key, group_flags);
         }
         // Free schedule: a ray that has just been through a list of instances (the scene root) and whose
         // nearest node is a model's root goes through that root now.  A wave's rays enter few distinct
@@ -1059,7 +1061,7 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
         const uint32_t g = uniform_value(ray->queue[0].group_id);
         uint32_t new_key = g;
         uint32_t group_flags;
-        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true>(g, ray, a, nullptr, nullptr, s_wave_pos[wave], s_wave_idx[wave], 0, tid,
+        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true, FREE>(g, ray, a, nullptr, nullptr, s_wave_pos[wave], s_wave_idx[wave], 0, tid,
                                                         new_key, group_flags);
         if (lane_id() == 0) {
             if (FREE) new_key = run_end_group(new_key, ray, a);
@@ -1092,7 +1094,7 @@ __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
         todo = false;
         const uint32_t g = uniform_value(key);  // every lane still here holds the same key
         MISC_STAMP(t_mesh0);
-        new_key = visit_mesh(g, ray, a);
+        new_key = visit_mesh<FREE>(g, ray, a);
         MISC_STAMP(t_mesh1);
         MISC_STAMP_ADD(a.frame, 2, t_mesh0, t_mesh1);
     }
@@ -1128,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
         switch ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) {
         case RT_SH_SPAWN: {
             bool started;
-            new_key = init_ray(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
+            new_key = init_ray<false>(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
             count_lanes(a.frame, kPrimarySpawned, started);
             break;
         }
@@ -1138,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
                 ray->queue[0].group_id = new_key = dead;
                 break;
             }
-            new_key = sky_or_light_shader(a, ray, ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_LIGHT);
+            new_key = sky_or_light_shader<false>(a, ray, ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_LIGHT);
             break;
         case RT_SH_MATERIAL: {
             if (trace_only) {
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
                 break;
             }
             const f32x4 color = *const_ptr<f32x4>(a.scene.grp + (g & kIdMask));
-            new_key = mat_shader(ray, make_float4(color.x, color.y, color.z, color.w), glob->shading);
+            new_key = mat_shader<false>(ray, make_float4(color.x, color.y, color.z, color.w), glob->shading);
             count_lanes(a.frame, kShadowSpawned, true);
             break;
         }
@@ -1344,8 +1346,8 @@ __global__ void k_export_rays(const RaySlot *rays, rt_ray_queue *out, uint32_t c
     rt_ray_queue q;
     q.weight[0] = s.weight.x;  q.weight[1] = s.weight.y;  q.weight[2] = s.weight.z;  q.weight[3] = s.weight.w;
     q.pixel = s.pixel;  q.type = s.type;  q.material_id = s.material_id;  q.queue_len = s.queue_len;
-    q.start_min[0] = s.start_min.x;  q.start_min[1] = s.start_min.y;  q.start_min[2] = s.start_min.z;  q.start_min[3] = s.start_min.w;
-    q.dir_max[0] = s.dir_max.x;  q.dir_max[1] = s.dir_max.y;  q.dir_max[2] = s.dir_max.z;  q.dir_max[3] = s.dir_max.w;
+    q.start_min[0] = s.start[0];  q.start_min[1] = s.start[1];  q.start_min[2] = s.start[2];  q.start_min[3] = s.t_min;
+    q.dir_max[0] = s.dir[0];  q.dir_max[1] = s.dir[1];  q.dir_max[2] = s.dir[2];  q.dir_max[3] = s.t_max;
     q.norm[0] = s.norm.x;  q.norm[1] = s.norm.y;  q.norm[2] = s.norm.z;  q.norm[3] = s.norm.w;
     q.root = rt_ray_hit{s.root.pos, s.root.group_id, {s.root.local0, s.root.local1}};
     q.orig = rt_ray_hit{s.orig.pos, s.orig.group_id, {s.orig.local0, s.orig.local1}};

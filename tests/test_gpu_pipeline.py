@@ -195,7 +195,9 @@ def test_free_schedule_keeps_the_step_invariants(bunny_scene_128):
         assert np.array_equal(np.sort(index["slot"]), np.arange(pool, dtype=np.uint32))
         shader = index["key"][:n] >> 28
         assert np.all((shader == L.SH_AABB) | (shader == L.SH_MESH) | (index["key"][:n] == 0))
-        assert np.array_equal(rays["queue"]["group_id"][index["slot"][:n], 0], index["key"][:n])
+        # a travelling ray's head is its key; a finished slot (key 0) keeps whatever its last sample left
+        live = index["key"][:n] != 0
+        assert np.array_equal(rays["queue"]["group_id"][index["slot"][:n][live], 0], index["key"][:n][live])
         assert int(g["pixel_offset"]) >= prev
         prev = int(g["pixel_offset"])
     c = rt.counters()

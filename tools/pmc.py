@@ -14,16 +14,27 @@ PASSES = {
     "write": ["WRITE_SIZE"],
     "l2": ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"],
     "grbm": ["GRBM_GUI_ACTIVE"],
+    # the vector memory path (not part of the default report: --passes ta,ta2,tcp_a,tcp_b,tcp_c,tcp_d)
+    "ta": ["TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum"],
+    "ta2": ["TA_DATA_STALLED_BY_TC_CYCLES_sum", "TA_TOTAL_WAVEFRONTS_sum"],
+    "tcp_a": ["TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum"],
+    "tcp_b": ["TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_TCR_TCP_STALL_CYCLES_sum"],
+    "tcp_c": ["TCP_UTCL1_TRANSLATION_MISS_sum", "TCP_UTCL1_TRANSLATION_HIT_sum", "TCP_UTCL1_REQUEST_sum",
+              "TCP_UTCL1_STALL_INFLIGHT_MAX_sum"],
+    "tcp_d": ["TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", "TCP_WRITE_TAGCONFLICT_STALL_CYCLES_sum", "TCP_LFIFO_STALL_CYCLES_sum",
+              "TCP_RFIFO_STALL_CYCLES_sum"],
 }
+DEFAULT_PASSES = "sq_a,sq_b,fetch,write,l2,grbm"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=96)
-    ap.add_argument("--passes", default=",".join(PASSES))
+    ap.add_argument("--passes", default=DEFAULT_PASSES)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc"))
     ap.add_argument("--extra", default="", help="extra bench.py arguments")
+    ap.add_argument("--summary", default="pmc_summary.json", help="file name of the summary under gpurun_out/")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
@@ -49,7 +60,7 @@ def main():
     out = {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in summary.items()}
     for k, cs in summary.items():
         out[k]["_dispatches"] = max(v[1] for v in cs.values())
-    path = os.path.join(os.path.dirname(args.out), "pmc_summary.json")
+    path = os.path.join(os.path.dirname(args.out), args.summary)
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     for k in sorted(out):
         if "process" in k or "sort" in k:
