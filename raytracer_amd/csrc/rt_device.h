@@ -24,12 +24,13 @@ struct RayHit {
 };
 
 // One ray slot, 256 bytes, 256-byte aligned.  Same content as the reference's RayQueue
-// (ray-tracer.h:164-170) plus the sample id.  The first 64 bytes are what every visit reads (three
+// (ray-tracer.h:164-170) plus the sample id (type and queue_len share a word).  The first 64 bytes are what every visit reads (three
 // 16-byte loads for the ray, one for the head of the queue); the fields a visit changes lie next to each
 // other so that one store covers them: (queue_len, t_min) after a visit, (material_id, queue_len, t_min,
 // t_max) after a hit.  The kernels are bound by the number of store requests, not by their bytes.
 struct alignas(256) RaySlot {
-    uint32_t pixel, type, material_id, queue_len;  //   0
+    uint32_t pixel, sample_id, material_id;        //   0
+    uint32_t type_len;                             //  12  type (ray kind, bounce count << 8) | queue_len << 24
     float t_min, t_max;                            //  16
     float start[3], dir[3];                        //  24, 36
     RayHit queue[RT_MAX_QUEUE_LEN];                //  48
@@ -37,7 +38,7 @@ struct alignas(256) RaySlot {
     float4 norm;                                   // 192
     RayHit orig;                                   // 208
     RayHit root;                                   // 224
-    uint32_t sample_id, pad0, pad1, pad2;          // 240
+    uint32_t pad[4];                               // 240
 };
 static_assert(sizeof(RaySlot) == 256, "ray slot must be 256 bytes");
 
@@ -137,7 +138,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b)
 }
 // The fields of a slot every visit reads, in registers: bytes 0-47 of the slot, three 16-byte requests.
 struct HotRay {
-    uint32_t pixel, type, material_id, queue_len;
+    uint32_t pixel, sample_id, material_id, type, queue_len;
     float t_min, t_max;
     V3 start, dir;
 };
@@ -148,23 +149,25 @@ __device__ __forceinline__ HotRay load_hot(const RaySlot *ray)
 {
     const uint4 a = *reinterpret_cast<const uint4 *>(ray);
     const float4 b = *reinterpret_cast<const float4 *>(&ray->t_min), c = *reinterpret_cast<const float4 *>(&ray->start[2]);
-    return HotRay{a.x, a.y, a.z, a.w, b.x, b.y, V3{b.z, b.w, c.x}, V3{c.y, c.z, c.w}};
+    return HotRay{a.x, a.y, a.z, a.w & 0xFFFFFFu, a.w >> 24, b.x, b.y, V3{b.z, b.w, c.x}, V3{c.y, c.z, c.w}};
 }
 __device__ __forceinline__ void store_hot(RaySlot *ray, const HotRay &h)
 {
-    *reinterpret_cast<uint4 *>(ray) = make_uint4(h.pixel, h.type, h.material_id, h.queue_len);
+    *reinterpret_cast<uint4 *>(ray) = make_uint4(h.pixel, h.sample_id, h.material_id, h.type | h.queue_len << 24);
     *reinterpret_cast<float4 *>(&ray->t_min) = make_float4(h.t_min, h.t_max, h.start.x, h.start.y);
     *reinterpret_cast<float4 *>(&ray->start[2]) = make_float4(h.start.z, h.dir.x, h.dir.y, h.dir.z);
 }
-// queue_len and t_min, one 8-byte request (save_queue, ray-tracer.cl:157-165)
-__device__ __forceinline__ void store_progress(RaySlot *ray, uint32_t queue_len, float t_min)
+// queue_len and t_min, one 8-byte request (save_queue, ray-tracer.cl:157-165); `type` is the ray's unchanged type
+__device__ __forceinline__ void store_progress(RaySlot *ray, uint32_t type, uint32_t queue_len, float t_min)
 {
-    *reinterpret_cast<u32x2_a4 *>(&ray->queue_len) = u32x2_a4{queue_len, __float_as_uint(t_min)};
+    *reinterpret_cast<u32x2_a4 *>(&ray->type_len) = u32x2_a4{type | queue_len << 24, __float_as_uint(t_min)};
 }
 // material_id, queue_len, t_min and t_max, one 16-byte request (insert_stop, ray-tracer.cl:173-203)
-__device__ __forceinline__ void store_commit(RaySlot *ray, uint32_t material_id, uint32_t queue_len, float t_min, float t_max)
+__device__ __forceinline__ void store_commit(RaySlot *ray, uint32_t material_id, uint32_t type, uint32_t queue_len, float t_min,
+                                             float t_max)
 {
-    *reinterpret_cast<u32x4_a4 *>(&ray->material_id) = u32x4_a4{material_id, queue_len, __float_as_uint(t_min), __float_as_uint(t_max)};
+    *reinterpret_cast<u32x4_a4 *>(&ray->material_id) =
+        u32x4_a4{material_id, type | queue_len << 24, __float_as_uint(t_min), __float_as_uint(t_max)};
 }
 
 __device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }

@@ -97,7 +97,8 @@ __device__ __forceinline__ uint32_t reset_ray(RaySlot *ray, HotRay h, uint32_t g
 // init_ray (ray-tracer.cl:56-74).  Sample ids at or beyond the limit take the dead-ray exit the
 // reference left commented out (ray-tracer.cl:61): the slot is left alone and parked in the last group.
 // LEAN: `root` is not stored again -- every slot of the pool got the camera's root when the frame was
-// initialised, and nothing else ever writes it.
+// initialised, and nothing else ever writes it -- and neither is the weight: a camera ray that has not
+// bounced has weight one, which is what ray_weight() gives for it without looking at the slot.
 template <bool LEAN>
 __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlobal *glob, RaySlot *ray,
                                              rt_hit_record *hits, uint32_t group_count, uint32_t sample, bool &started)
@@ -119,9 +120,9 @@ __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlob
     h.type = RT_RAY_PRIMARY;
     h.start = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
     h.dir = normalize((tl + dx * x) + dy * y);
-    ray->weight = make_float4(1, 1, 1, 1);
+    if (!LEAN) ray->weight = make_float4(1, 1, 1, 1);
     if (!LEAN) ray->root = RayHit{0.0f, cam.root_group, cam.root_local, 0u};
-    ray->sample_id = sample;
+    h.sample_id = sample;
     if (sample < glob->hit_capacity) hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     return reset_ray<LEAN>(ray, h, cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
 }
@@ -260,14 +261,14 @@ __device__ __forceinline__ void load_pending(OldQueue &old, const RaySlot *ray, 
 
 // save_queue + copy_queue for a queue that is either the shifted old one or empty
 // (ray-tracer.cl:154-168 and 184-203).  Returns the new sort key.
-__device__ __forceinline__ uint32_t store_shifted(RaySlot *ray, const OldQueue &old, uint32_t len, float head_pos,
+__device__ __forceinline__ uint32_t store_shifted(RaySlot *ray, const OldQueue &old, uint32_t type, uint32_t len, float head_pos,
                                                   uint32_t end_group)
 {
 #pragma unroll
     for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
         if ((uint32_t)i < len) ray->queue[i] = old.e[i + 1];
     if (len) {
-        store_progress(ray, len, head_pos);
+        store_progress(ray, type, len, head_pos);
         return old.e[1].group_id;
     }
     // Empty: the head becomes the ray's end group.  queue[0].pos keeps its value (the reference leaves
@@ -289,14 +290,23 @@ __device__ __forceinline__ void area_add(float4 *area, uint32_t pixel, float r, 
     unsafeAtomicAdd(px + 3, w);
 }
 
+// The colour weight of a ray: one for a camera ray that has not bounced, else what the slot holds.
+__device__ __forceinline__ float4 ray_weight(const RaySlot *ray, uint32_t type)
+{
+    float4 w = make_float4(1, 1, 1, 1);
+    if (type != RT_RAY_PRIMARY) w = ray->weight;
+    return w;
+}
+
 // LEAN (free schedule): the slot of a finished sample is not marked; its key says it all and the next
 // sample overwrites the queue.
 template <bool LEAN>
 __device__ __forceinline__ uint32_t sky_or_light_shader(const ProcessArgs &a, RaySlot *ray, bool is_light)
 {
-    const float4 w = ray->weight;
+    const uint4 meta = *reinterpret_cast<const uint4 *>(ray);  // pixel, sample, end group, type and queue length
+    const float4 w = ray_weight(ray, meta.w & 0xFFFFFFu);
     const float cr = is_light ? 1.0f : 0.5f;
-    area_add(a.frame.area, ray->pixel, w.x * cr, w.y * 1.0f, w.z * 1.0f, w.w * 1.0f);
+    area_add(a.frame.area, meta.x, w.x * cr, w.y * 1.0f, w.z * 1.0f, w.w * 1.0f);
     if (!LEAN) ray->queue[0].group_id = RT_SPAWN_GROUP;
     return RT_SPAWN_GROUP;
 }
@@ -313,7 +323,7 @@ __device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, HotRay h, float4
         out = dir - norm * (2 * dot(dir, norm));
     } else {
         const V3 up = dot(dir, norm) > 0 ? v3(-norm.x, -norm.y, -norm.z) : norm;
-        const uint32_t base = hash32((shading >> 8) ^ ray->sample_id * 0x9E3779B9u ^ depth * 0x85EBCA6Bu);
+        const uint32_t base = hash32((shading >> 8) ^ h.sample_id * 0x9E3779B9u ^ depth * 0x85EBCA6Bu);
         float x1 = 0, x2 = 0, s = 0;
         for (uint32_t k = 0; k < 8; k++) {
             const float a = 2 * uniform01(hash32(base + 2 * k)) - 1, b = 2 * uniform01(hash32(base + 2 * k + 1)) - 1;
@@ -327,12 +337,13 @@ __device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, HotRay h, float4
         const V3 v = up + v3(x1 * r, x2 * r, 1 - 2 * s);
         const float len2 = dot(v, v);
         out = len2 > 1e-12f ? v * (1.0f / sqrtf(len2)) : up;
-        float4 w = ray->weight;
+        float4 w = ray_weight(ray, h.type);
         w.x *= color.x;
         w.y *= color.y;
         w.z *= color.z;
         ray->weight = w;
     }
+    if ((shading & 15u) == RT_SHADE_MIRROR && h.type == RT_RAY_PRIMARY) ray->weight = make_float4(1, 1, 1, 1);  // no longer implied
     h.type = RT_RAY_PRIMARY | (depth + 1) << 8;
     h.start = h.start + dir * h.t_max;
     h.dir = out;
@@ -359,7 +370,7 @@ __device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color, uint3
     const float sw = spec * color.w;
     const V3 c = v3(color.x + sw, color.y + sw, color.z + sw) * lambert;
 
-    float4 w = ray->weight;
+    float4 w = ray_weight(ray, h.type);
     w.x *= c.x;
     w.y *= c.y;
     w.z *= c.z;
@@ -497,16 +508,16 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     if (hit) {
         if (shadow) {
             unsafeAtomicAdd(reinterpret_cast<float *>(&a.frame.area[h.pixel]) + 3, shadow_weight);
-            store_commit(ray, end_group, new_len, new_min, h.t_max);
+            store_commit(ray, end_group, h.type, new_len, new_min, h.t_max);
         } else {
             ray->norm = make_float4(nw.x, nw.y, nw.z, 0.0f);
             if (!LEAN) ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
             // the record is the camera ray's hit: a sample that has bounced keeps it
             if (h.type == RT_RAY_PRIMARY && sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
-            store_commit(ray, end_group, new_len, new_min, best);
+            store_commit(ray, end_group, h.type, new_len, new_min, best);
         }
     } else if (len) {
-        store_progress(ray, len, head.pos);
+        store_progress(ray, h.type, len, head.pos);
     }
 #pragma unroll
     for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
@@ -925,7 +936,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     }
     // save_queue (ray-tracer.cl:157-165)
     if (k) {
-        store_progress(ray, k, head.pos);
+        store_progress(ray, h.type, k, head.pos);
         new_key = first_group;
     } else {
         const uint32_t end_group = h.material_id;
@@ -1153,11 +1164,11 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
             break;
         }
         default: {  // unknown shader type: the reference falls through to the pop (ray-tracer.cl:152-165)
-            const uint32_t queue_len = ray->queue_len;
+            const uint32_t type_len = ray->type_len, queue_len = type_len >> 24;
             const float head_pos = ray->queue[0].pos;
             OldQueue old;
             load_pending(old, ray, queue_len);
-            new_key = store_shifted(ray, old, queue_len - 1, head_pos, ray->material_id);
+            new_key = store_shifted(ray, old, type_len & 0xFFFFFFu, queue_len - 1, head_pos, ray->material_id);
             break;
         }
         }
@@ -1345,7 +1356,7 @@ __global__ void k_export_rays(const RaySlot *rays, rt_ray_queue *out, uint32_t c
     const RaySlot &s = rays[i];
     rt_ray_queue q;
     q.weight[0] = s.weight.x;  q.weight[1] = s.weight.y;  q.weight[2] = s.weight.z;  q.weight[3] = s.weight.w;
-    q.pixel = s.pixel;  q.type = s.type;  q.material_id = s.material_id;  q.queue_len = s.queue_len;
+    q.pixel = s.pixel;  q.type = s.type_len & 0xFFFFFFu;  q.material_id = s.material_id;  q.queue_len = s.type_len >> 24;
     q.start_min[0] = s.start[0];  q.start_min[1] = s.start[1];  q.start_min[2] = s.start[2];  q.start_min[3] = s.t_min;
     q.dir_max[0] = s.dir[0];  q.dir_max[1] = s.dir[1];  q.dir_max[2] = s.dir[2];  q.dir_max[3] = s.t_max;
     q.norm[0] = s.norm.x;  q.norm[1] = s.norm.y;  q.norm[2] = s.norm.z;  q.norm[3] = s.norm.w;
