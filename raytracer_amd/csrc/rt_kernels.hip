@@ -94,6 +94,31 @@ __device__ __forceinline__ uint32_t reset_ray(RaySlot *ray, HotRay h, uint32_t g
     return group_id;
 }
 
+// The hot fields of sample number `sample` as init_ray and reset_ray set them (ray-tracer.cl:10-16, 56-74):
+// a camera ray through the sample's sub-pixel position, about to enter the camera's root group.
+__device__ __forceinline__ HotRay camera_ray(const rt_camera &cam, const DevGlobal *glob, uint32_t sample)
+{
+    const uint32_t total = cam.width * cam.height;
+    uint32_t sx, sy;
+    deinterleave(sample / total, sx, sy);
+    const uint32_t pixel = sample % total;
+    const float x = (float)(pixel % cam.width) + subpixel(sx);
+    const float y = (float)(pixel / cam.width + glob->row_offset) + subpixel(sy);
+    const V3 tl = v3(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
+    const V3 dx = v3(cam.dx[0], cam.dx[1], cam.dx[2]), dy = v3(cam.dy[0], cam.dy[1], cam.dy[2]);
+    HotRay h;
+    h.pixel = pixel;
+    h.sample_id = sample;
+    h.material_id = RT_SKY_GROUP;
+    h.type = RT_RAY_PRIMARY;
+    h.queue_len = 1;
+    h.t_min = 0.001f;
+    h.t_max = INFINITY;
+    h.start = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
+    h.dir = normalize((tl + dx * x) + dy * y);
+    return h;
+}
+
 // init_ray (ray-tracer.cl:56-74).  Sample ids at or beyond the limit take the dead-ray exit the
 // reference left commented out (ray-tracer.cl:61): the slot is left alone and parked in the last group.
 // LEAN: `root` is not stored again -- every slot of the pool got the camera's root when the frame was
@@ -106,25 +131,10 @@ __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlob
     const uint32_t limit = glob->sample_limit;
     started = !(limit && sample >= limit);
     if (!started) return group_count - 1;
-    const uint32_t total = cam.width * cam.height;
-    uint32_t sx, sy;
-    deinterleave(sample / total, sx, sy);
-    const uint32_t pixel = sample % total;
-    const float x = (float)(pixel % cam.width) + subpixel(sx);
-    const float y = (float)(pixel / cam.width + glob->row_offset) + subpixel(sy);
-
-    const V3 tl = v3(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
-    const V3 dx = v3(cam.dx[0], cam.dx[1], cam.dx[2]), dy = v3(cam.dy[0], cam.dy[1], cam.dy[2]);
-    HotRay h;
-    h.pixel = pixel;
-    h.type = RT_RAY_PRIMARY;
-    h.start = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
-    h.dir = normalize((tl + dx * x) + dy * y);
     if (!LEAN) ray->weight = make_float4(1, 1, 1, 1);
     if (!LEAN) ray->root = RayHit{0.0f, cam.root_group, cam.root_local, 0u};
-    h.sample_id = sample;
     if (sample < glob->hit_capacity) hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    return reset_ray<LEAN>(ray, h, cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
+    return reset_ray<LEAN>(ray, camera_ray(cam, glob, sample), cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
 }
 
 // One atomic per wave for a per-lane event count (each counted lane adds `weight`, wave-uniform), to
@@ -646,10 +656,10 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
 // caller hands every lane that ray's group and slot): the scan and the candidate sort are done by
 // wave_visit_one in the wave's lists c_pos/c_idx with the reference's limit of 64 candidates, and
 // only the lane `owner` merges and stores.
-template <int CAP, int THREADS, bool COOP, bool LEAN>
+template <int CAP, int THREADS, bool COOP, bool LEAN, bool FRESH = false>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
                                            uint8_t (*s_idx)[THREADS], float *c_pos, uint16_t *c_idx, uint32_t owner,
-                                           uint32_t tid, uint32_t &new_key, uint32_t &group_flags)
+                                           uint32_t tid, uint32_t &new_key, uint32_t &group_flags, uint32_t sample = 0)
 {
     AABB_STAMP(t_start);
     MERGE_STAMP(t_m_start);
@@ -658,9 +668,15 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     group_flags = grp.z;
     // What the scan needs from the slot (ray and head of the queue: its first 64 bytes) is requested
     // now.  No load is issued once the stores of the merge begin.
-    const HotRay h = load_hot(ray);
-    const uint32_t old_len = h.queue_len;
-    const RayHit head = ray->queue[0];
+    // FRESH: the visit that starts sample number `sample`.  Its slot has not been written: the ray is worked
+    // out here, there are no pending entries, and the slot's hot fields are stored whole at the end.
+    HotRay h = FRESH ? camera_ray(a.cam, a.frame.glob, sample) : load_hot(ray);
+    const RayHit head = FRESH ? RayHit{0.001f, a.cam.root_group, a.cam.root_local, 0u} : ray->queue[0];
+    const uint32_t old_len = FRESH ? 1u : h.queue_len;
+    auto put_fresh_sample_in_its_slot = [&]() {  // for the kernel that redoes a visit this one gives up
+        store_hot(ray, h);
+        ray->queue[0] = head;
+    };
     const LocalRay lr = make_local(g, h, head.local0, a.scene.mat);
     const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
     if (!COOP) count_lanes(a.frame, kBoxTests, true, count);  // a redone visit was counted the first time
@@ -677,7 +693,10 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     // in the order the reference's loop does (shader.cl:84-99).  The device copies of both lists are
     // filled up with entries no ray can enter and followed by readable spare entries: the loops have
     // no tail handling and always have the next 128 bytes in flight while the current ones are tested.
-    if (count > kMaxClusteredBoxes) return false;  // places in such a list do not fit the columns' bytes
+    if (count > kMaxClusteredBoxes) {  // places in such a list do not fit the columns' bytes
+        if (FRESH) put_fresh_sample_in_its_slot();
+        return false;
+    }
     asm volatile("" ::"v"(inv_dir.x), "v"(inv_dir.y), "v"(inv_dir.z), "v"(lr.start.x));
     AABB_STAMP(t_loaded);
     bool spill = false;
@@ -801,7 +820,10 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     AABB_STAMP(t_scanned);
     AABB_STAMP_ADD(a.frame, 0, t_start, t_loaded);
     AABB_STAMP_ADD(a.frame, 1, t_loaded, t_scanned);
-    if (spill) return false;
+    if (spill) {
+        if (FRESH) put_fresh_sample_in_its_slot();
+        return false;
+    }
     }
     // The pending entries are fetched only now (two visits in three have none): held across the scan
     // they would cost 28 registers, i.e. two of the seven waves a SIMD holds of this kernel.  The hit
@@ -935,8 +957,16 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) place_candidate(j);
     }
     // save_queue (ray-tracer.cl:157-165)
+    if (FRESH) {
+        // (a sample that enters nothing keeps queue_len and t_min as reset_ray set them, as below)
+        if (k) {
+            h.queue_len = k;
+            h.t_min = head.pos;
+        }
+        store_hot(ray, h);
+    }
     if (k) {
-        store_progress(ray, h.type, k, head.pos);
+        if (!FRESH) store_progress(ray, h.type, k, head.pos);
         new_key = first_group;
     } else {
         const uint32_t end_group = h.material_id;
@@ -992,25 +1022,40 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
     uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
     if (FREE ? shader == RT_SH_MESH : shader != RT_SH_AABB) return;
     RaySlot *ray = &a.frame.rays[entry.slot];
+    bool fresh = false;  // this lane starts a sample whose slot has not been written yet
+    uint32_t sample = 0;
     if (FREE) {
         if (key == RT_SPAWN_GROUP) {  // a finished slot: the next sample starts here and visits the root below
-            bool started;
-            key = init_ray<true>(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
-            count_lanes(a.frame, kPrimarySpawned, started);
-            asm volatile("" ::: "memory");  // the visit reads the slot init_ray has just written
+            sample = index + glob->g.pixel_offset;
+            const uint32_t limit = glob->sample_limit;
+            fresh = !(limit && sample >= limit);
+            count_lanes(a.frame, kPrimarySpawned, fresh);
+            key = fresh ? a.cam.root_group : a.group_count - 1;
+            if (fresh && sample < glob->hit_capacity) a.frame.hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
         }
         if (shader != RT_SH_AABB) {
             // a sample beyond the limit (dead-ray bin), a scene whose root is a leaf, or a shader key left by
             // rt_init_frame/rt_trace_closest: no box visit
+            if (fresh) reset_ray<true>(ray, camera_ray(a.cam, glob, sample), a.cam.root_group, a.cam.root_local, 0u, RT_SKY_GROUP);
             a.frame.next[index] = rt_index_pair{run_end_group(key, ray, a), entry.slot};
             return;
         }
     }
 
     uint32_t new_key = key;
-    bool done = true;
-    for (int round = 0;; round++) {
+    bool done = true, visit = true;
+    if (FREE && fresh) {
+        // The samples that start here all enter the camera's root: a visit of its own, with the ray worked out in
+        // registers and no pending entries.  A ray that comes out of an instance list at a model's root goes on below.
+        uint32_t group_flags = 0;
+        done = visit_aabb<kAabbCap, kAabbThreads, false, true, true>(uniform_value(key), ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid,
+                                                                     new_key, group_flags, sample);
+        visit = done && (group_flags & RT_F_LOCAL0) && ((new_key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_AABB;
+        asm volatile("" ::: "memory");  // the next visit reads what this one has stored to the slot
+        if (visit) key = new_key;
+    }
+    if (visit) for (int round = 0;; round++) {
         uint32_t group_flags = 0;
         bool todo = true;
         while (todo) {

@@ -5,7 +5,7 @@ from raytracer_amd import api, scene as S, layout as L
 dragon = os.path.join(tempfile.gettempdir(), "rt_dragon_standin_tool.ply")
 if not os.path.exists(dragon): S.write_standin_ply(dragon)
 sc = S.build_scene([S.BUNNY, dragon], 1920, 1080, 1920*1080)
-rt = api.RayTracer(sc, warp_width=64); rt.init_frame(); rt.make_step(120); rt.sync()
+rt = api.RayTracer(sc, warp_width=64, free_schedule="--reference" not in sys.argv); rt.init_frame(); rt.make_step(120); rt.sync()
 rays, index, groups = rt.dump_state()
 n = int(rt.global_data()["ray_count"][0])
 live = index[:n]
