@@ -23,14 +23,21 @@ struct RayHit {
     uint32_t local0, local1;
 };
 
-// One ray slot, 256 bytes, 256-byte aligned.  Same content as the reference's RayQueue
-// (ray-tracer.h:164-170) plus the sample id (type and queue_len share a word).  The first 64 bytes are what every visit reads (three
-// 16-byte loads for the ray, one for the head of the queue); the fields a visit changes lie next to each
-// other so that one store covers them: (queue_len, t_min) after a visit, (material_id, queue_len, t_min,
-// t_max) after a hit.  The kernels are bound by the number of store requests, not by their bytes.
+// One ray slot, 256 bytes, 256-byte aligned: what the reference keeps per ray in its RayQueue
+// (ray-tracer.h:164-170) plus the sample id.  The kernels are bound by the memory traffic of these slots --
+// 128-byte lines fetched, lines dirtied, store requests -- so the layout follows the accesses:
+//   * bytes 0-47 are what every visit reads (three 16-byte loads), byte 48 is the head of the queue; the fields
+//     a visit changes lie next to each other so that one store covers them -- (type_len, t_min) after a visit,
+//     (material_id, type_len, t_min, t_max) after a hit;
+//   * the first 128-byte line also holds four pending entries: most visits touch this line only.
+// The reference schedule keeps the pending entries as the reference does, queue[1..queue_len) nearest first,
+// stale entries included.  The free schedule keeps them as a stack, nearest on top: queue[i], i >= 1, lies in
+// queue[queue_len - i].  Popping the head then moves one entry, a merge stores only the entries that change
+// place, and entries a hit has made unreachable (pos >= t_max: always the far end) stay until the next merge or
+// pop counts them out.  A shadow ray's t_max, infinite in the reference for all its life, is that reach only.
 struct alignas(256) RaySlot {
     uint32_t pixel, sample_id, material_id;        //   0
-    uint32_t type_len;                             //  12  type (ray kind, bounce count << 8) | queue_len << 24
+    uint32_t type_len;                             //  12  type (ray kind, bounces << 8) | queue_len << 24
     float t_min, t_max;                            //  16
     float start[3], dir[3];                        //  24, 36
     RayHit queue[RT_MAX_QUEUE_LEN];                //  48
@@ -138,7 +145,8 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b)
 }
 // The fields of a slot every visit reads, in registers: bytes 0-47 of the slot, three 16-byte requests.
 struct HotRay {
-    uint32_t pixel, sample_id, material_id, type, queue_len;
+    uint32_t pixel, sample_id, material_id;
+    uint32_t type, queue_len;  // (one word in the slot)
     float t_min, t_max;
     V3 start, dir;
 };

@@ -478,16 +478,8 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     // Miss: pop the head (ray-tracer.cl:154-165).  Hit: insert_stop (ray-tracer.cl:173-203).  What a
     // hit still needs from memory (shading normal, sample id, or the shadow weight) is loaded before
     // the first store of this visit.
-    // The pending entries are fetched only now: held across the scan they would cost 28 registers.
-    RayHit q[RT_MAX_QUEUE_LEN];
-    q[0] = head;
-#pragma unroll
-    for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
-        q[i] = RayHit{0.0f, 0u, 0u, 0u};
-        if ((uint32_t)i < queue_len) q[i] = ray->queue[i];
-    }
     const bool hit = hit_index != 0xFFFFFFFFu, shadow = (h.type & 0xFFu) == RT_RAY_SHADOW;  // (bounce count above the low byte)
-    uint32_t len = queue_len - 1, end_group = h.material_id, sid = 0xFFFFFFFFu;
+    uint32_t end_group = h.material_id, sid = 0xFFFFFFFFu;
     float shadow_weight = 0;
     V3 nw = v3(0, 0, 0);
     if (hit) {
@@ -505,41 +497,89 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
             nw = (lr.m0 * nn.x + lr.m1 * nn.y) + lr.m2 * nn.z;
             end_group = grp.w;
         }
-        // pending nodes that start at or beyond the hit are dropped, and everything after them
-#pragma unroll
-        for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
-            if ((uint32_t)i < len && q[i + 1].pos >= best) len = i;
     }
-
-    // save_queue + copy_queue (ray-tracer.cl:157-168, 195-203).  An emptied queue leaves queue_len and t_min
-    // alone; with a hit, the end group and the new t_max go out in the same request as those two.
-    const uint32_t new_len = len ? len : queue_len;
-    const float new_min = len ? head.pos : h.t_min;
-    if (hit) {
+    const float new_max = hit && !shadow ? best : h.t_max;
+    auto commit_hit = [&](uint32_t len, float t_min) {  // what a hit leaves in the slot beside the queue
         if (shadow) {
             unsafeAtomicAdd(reinterpret_cast<float *>(&a.frame.area[h.pixel]) + 3, shadow_weight);
-            store_commit(ray, end_group, h.type, new_len, new_min, h.t_max);
         } else {
             ray->norm = make_float4(nw.x, nw.y, nw.z, 0.0f);
             if (!LEAN) ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
             // the record is the camera ray's hit: a sample that has bounced keeps it
             if (h.type == RT_RAY_PRIMARY && sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
-            store_commit(ray, end_group, h.type, new_len, new_min, best);
         }
-    } else if (len) {
-        store_progress(ray, h.type, len, head.pos);
+        store_commit(ray, end_group, h.type, len, t_min, new_max);
+    };
+
+    if (LEAN) {
+        // Stack of pending entries.  The nearest one becomes the head unless it starts at or beyond the ray's
+        // reach: then so do all the others, and the queue is empty.  A hit shortens the reach and leaves the stack
+        // alone (the reference drops the entries beyond the hit on the spot).  Not so for a shadow ray: its hits do
+        // not shorten its reach -- boxes beyond them are still entered afterwards -- so its entries beyond the hit
+        // are taken out now, and the nearer ones move down to the bottom of the stack.
+        uint32_t len = queue_len - 1;  // entries after this visit, the new head included
+        RayHit next = RayHit{0.0f, 0u, 0u, 0u};
+        bool moved = false;
+        if (hit && shadow && len > 1) {
+            uint32_t keep = len;
+            RayHit e[RT_MAX_QUEUE_LEN];
+#pragma unroll
+            for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
+                e[i] = RayHit{0.0f, 0u, 0u, 0u};
+                if ((uint32_t)i <= len) e[i] = ray->queue[queue_len - i];
+            }
+#pragma unroll
+            for (int i = 1; i < RT_MAX_QUEUE_LEN; i++)
+                if ((uint32_t)i <= keep && e[i].pos >= best) keep = i - 1;
+            if (keep != len) {
+#pragma unroll
+                for (int i = 2; i < RT_MAX_QUEUE_LEN; i++)
+                    if ((uint32_t)i <= keep) ray->queue[keep + 1 - i] = e[i];
+                len = keep;
+                next = e[1];
+                moved = true;
+            }
+        }
+        if (len && !moved) next = ray->queue[len];
+        if (len && next.pos >= (hit && shadow ? best : new_max)) len = 0;
+        if (len) {
+            if (hit) commit_hit(len, head.pos);
+            else store_progress(ray, h.type, len, head.pos);
+            ray->queue[0] = next;
+            return next.group_id;
+        }
+        if (hit) commit_hit(queue_len, h.t_min);
+        return end_group;  // (the caller runs that group's shader right away: the head is not touched)
     }
+
+    // The pending entries are fetched only now: held across the scan they would cost 28 registers.
+    RayHit q[RT_MAX_QUEUE_LEN];
+    q[0] = head;
+#pragma unroll
+    for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
+        q[i] = RayHit{0.0f, 0u, 0u, 0u};
+        if ((uint32_t)i < queue_len) q[i] = ray->queue[i];
+    }
+    uint32_t len = queue_len - 1;
+    if (hit) {
+        // pending nodes that start at or beyond the hit are dropped, and everything after them
+#pragma unroll
+        for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
+            if ((uint32_t)i < len && q[i + 1].pos >= best) len = i;
+    }
+    // save_queue + copy_queue (ray-tracer.cl:157-168, 195-203).  An emptied queue leaves queue_len and t_min
+    // alone; with a hit, the end group and the new t_max go out in the same request as those two.
+    if (hit) commit_hit(len ? len : queue_len, len ? head.pos : h.t_min);
+    else if (len) store_progress(ray, h.type, len, head.pos);
 #pragma unroll
     for (int i = 0; i < RT_MAX_QUEUE_LEN - 1; i++)
         if ((uint32_t)i < len) ray->queue[i] = q[i + 1];
     if (len) return q[1].group_id;
     // Empty: the head becomes the ray's end group; queue[0].pos keeps its value (the reference leaves
     // it indeterminate, ray-tracer.cl:164,201).
-    if (!LEAN) {
-        ray->queue[0].group_id = end_group;
-        ray->queue[0].local0 = 0;
-        ray->queue[0].local1 = 0;
-    }
+    ray->queue[0].group_id = end_group;
+    ray->queue[0].local0 = 0;
+    ray->queue[0].local1 = 0;
     return end_group;
 }
 
@@ -673,6 +713,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     HotRay h = FRESH ? camera_ray(a.cam, a.frame.glob, sample) : load_hot(ray);
     const RayHit head = FRESH ? RayHit{0.001f, a.cam.root_group, a.cam.root_local, 0u} : ray->queue[0];
     const uint32_t old_len = FRESH ? 1u : h.queue_len;
+    const float reach = h.t_max;
     auto put_fresh_sample_in_its_slot = [&]() {  // for the kernel that redoes a visit this one gives up
         store_hot(ray, h);
         ray->queue[0] = head;
@@ -833,7 +874,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 #pragma unroll
     for (int i = 1; i < RT_MAX_QUEUE_LEN; i++) {
         q[i] = RayHit{0.0f, 0u, 0u, 0u};
-        if ((uint32_t)i < old_len) q[i] = ray->queue[i];
+        if ((uint32_t)i < old_len) q[i] = ray->queue[LEAN ? old_len - i : i];
     }
 
     // sort_hits (ray-tracer.cl:90-117): the reference's compare-exchange network, run with
@@ -891,30 +932,48 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     MERGE_STAMP(t_m1);
     MERGE_STAMP_ADD(a.frame, 0, t_m0, t_m1);
 #endif
-    const uint32_t merged = old_len - 1 + n;
+    // Free schedule: pending entries that start at or beyond the ray's reach -- a hit since they were queued has
+    // made them unreachable, and with them all that follow (see RaySlot) -- are counted out first.
+    uint32_t live_len = old_len;
+    if (LEAN && !FRESH) {
+#pragma unroll
+        for (int i = 1; i < RT_MAX_QUEUE_LEN; i++)
+            if ((uint32_t)i < live_len && q[i].pos >= reach) live_len = i;
+    }
+    const uint32_t merged = live_len - 1 + n;
     const bool overflow = merged >= RT_MAX_QUEUE_LEN;
     const uint32_t k = overflow ? RT_MAX_QUEUE_LEN : merged;
     RayHit root = RayHit{0.0f, 0u, 0u, 0u};
     if (overflow) root = ray->root;  // ray-tracer.cl:228-231: the 8th entry keeps its position, restarts from the root later
     uint32_t first_group = 0;
-    auto place = [&](uint32_t at, RayHit e) {
+    // Stack: queue[at] of the merged queue lies in queue[k - at]; `was` is where the entry lay before (kNowhere: a new one).
+    // A pending entry stays where it is unless a candidate lands behind it or entries beyond it were counted out:
+    // such entries are not stored again.
+    constexpr uint32_t kNowhere = 0xFFFFFFFFu;
+    auto place = [&](uint32_t at, RayHit e, uint32_t was) {
         if (at >= RT_MAX_QUEUE_LEN) return;
         if (at == RT_MAX_QUEUE_LEN - 1) {
             e.group_id = root.group_id;
             e.local0 = root.local0;
             e.local1 = root.local1;
+            was = kNowhere;
         }
         if (at == 0) first_group = e.group_id;
 #ifndef RT_ABLATE_STORES
-        ray->queue[at] = e;
+        if (LEAN) {
+            const uint32_t to = at ? k - at : 0u;
+            if (to != was) ray->queue[to] = e;
+        } else {
+            ray->queue[at] = e;
+        }
 #else
         asm volatile("" ::"v"(e.pos), "v"(e.group_id), "v"(e.local0), "v"(e.local1), "v"(at));
 #endif
     };
     // The counts run over 7 x 8 pairs in full; most visits have few pending entries and few candidates, so the
     // loops are cut, wave-uniformly, at the largest numbers any lane of the wave has (in halves of four).
-    const bool many_old = __ballot(old_len > 4) != 0, many_new = __ballot(n > 4) != 0;
-    const bool some_old = __ballot(old_len > 1) != 0;
+    const bool many_old = __ballot(live_len > 4) != 0, many_new = __ballot(n > 4) != 0;
+    const bool some_old = __ballot(live_len > 1) != 0;
     auto candidates_before = [&](float pos) {  // candidates strictly before a pending entry
         uint32_t c = 0;
 #pragma unroll
@@ -928,27 +987,28 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     auto pending_not_after = [&](float pos) {  // pending entries a candidate goes behind
         uint32_t c = 0;
 #pragma unroll
-        for (int i = 1; i < 4; i++) c += ((uint32_t)i < old_len && !(pos < q[i].pos)) ? 1u : 0u;
+        for (int i = 1; i < 4; i++) c += ((uint32_t)i < live_len && !(pos < q[i].pos)) ? 1u : 0u;
         if (many_old) {
 #pragma unroll
-            for (int i = 4; i < RT_MAX_QUEUE_LEN; i++) c += ((uint32_t)i < old_len && !(pos < q[i].pos)) ? 1u : 0u;
+            for (int i = 4; i < RT_MAX_QUEUE_LEN; i++) c += ((uint32_t)i < live_len && !(pos < q[i].pos)) ? 1u : 0u;
         }
         return c;
     };
+    auto place_pending = [&](int i) {
+        if ((uint32_t)i < live_len) place(i - 1 + candidates_before(q[i].pos), q[i], old_len - i);
+    };
     if (some_old) {
 #pragma unroll
-        for (int i = 1; i < 4; i++)
-            if ((uint32_t)i < old_len) place(i - 1 + candidates_before(q[i].pos), q[i]);
+        for (int i = 1; i < 4; i++) place_pending(i);
         if (many_old) {
 #pragma unroll
-            for (int i = 4; i < RT_MAX_QUEUE_LEN; i++)
-                if ((uint32_t)i < old_len) place(i - 1 + candidates_before(q[i].pos), q[i]);
+            for (int i = 4; i < RT_MAX_QUEUE_LEN; i++) place_pending(i);
         }
     }
     auto place_candidate = [&](int j) {
         if ((uint32_t)j < n)
             place(j + (some_old ? pending_not_after(cand_pos[j]) : 0u),
-                  RayHit{cand_pos[j], cand_group[j], take0 ? cand_local[j] : head.local0, take1 ? cand_local[j] : head.local1});
+                  RayHit{cand_pos[j], cand_group[j], take0 ? cand_local[j] : head.local0, take1 ? cand_local[j] : head.local1}, kNowhere);
     };
 #pragma unroll
     for (int j = 0; j < 4; j++) place_candidate(j);
@@ -1393,8 +1453,9 @@ __global__ __launch_bounds__(kGroupThreads) void k_set_ray_index(const DevGlobal
     if (index < count) dst[index] = e;  // always true for consistent group data; keeps bad caller data from faulting
 }
 
-// Converts ray slots to the reference's RayQueue layout (ray-tracer.h:164-170) for rt_dump_state.
-__global__ void k_export_rays(const RaySlot *rays, rt_ray_queue *out, uint32_t count)
+// Converts ray slots to the reference's RayQueue layout (ray-tracer.h:164-170) for rt_dump_state.  `stack`: the
+// slots keep their pending entries the free schedule's way (entries behind queue_len read as zero).
+__global__ void k_export_rays(const RaySlot *rays, rt_ray_queue *out, uint32_t count, bool stack)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -1407,8 +1468,11 @@ __global__ void k_export_rays(const RaySlot *rays, rt_ray_queue *out, uint32_t c
     q.norm[0] = s.norm.x;  q.norm[1] = s.norm.y;  q.norm[2] = s.norm.z;  q.norm[3] = s.norm.w;
     q.root = rt_ray_hit{s.root.pos, s.root.group_id, {s.root.local0, s.root.local1}};
     q.orig = rt_ray_hit{s.orig.pos, s.orig.group_id, {s.orig.local0, s.orig.local1}};
-    for (int k = 0; k < RT_MAX_QUEUE_LEN; k++)
-        q.queue[k] = rt_ray_hit{s.queue[k].pos, s.queue[k].group_id, {s.queue[k].local0, s.queue[k].local1}};
+    for (int k = 0; k < RT_MAX_QUEUE_LEN; k++) {
+        RayHit e = s.queue[k];
+        if (stack && k) e = (uint32_t)k < q.queue_len ? s.queue[q.queue_len - k] : RayHit{0.0f, 0u, 0u, 0u};
+        q.queue[k] = rt_ray_hit{e.pos, e.group_id, {e.local0, e.local1}};
+    }
     out[i] = q;
 }
 
@@ -1485,7 +1549,7 @@ void launch_resolve(const LaunchCtx &c, void *out)
 
 void launch_export_rays(const LaunchCtx &c, rt_ray_queue *out)
 {
-    k_export_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(c.frame.rays, out, c.pool);
+    k_export_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(c.frame.rays, out, c.pool, c.free_schedule);
 }
 
 }  // namespace rtd

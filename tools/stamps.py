@@ -18,6 +18,6 @@ st = rt.debug_stamps()
 names = {"1": ["load+transform", "box scan", "hit network", "merge+store"],
          "3": ["box visits (waves, M)", "in the one-octant scan", "scene-root visits", "scene root in the one-octant scan"],
          "4": ["merge: ids + pending landed (after issue)", "merge: ranks + stores issued", "merge: stores acknowledged", "whole box visit"],
-         "2": ["leaf: load", "leaf: scan", "leaf: whole visit", "all cases (incl. leaf)"]}[WHICH]
+         "2": ["leaf: load", "leaf: scan", "leaf: whole visit", "all cases (incl. leaf)"]}[WHICH[-1]]
 for n, v in zip(names, st):
     print(f"{n:40s} {v/32/1e6:10.2f} M per step ({v/32:.0f})")
