@@ -615,8 +615,18 @@ constexpr int kAabbCap = RT_AABB_CAP;
 __device__ __forceinline__ bool box_test(const f32x8 b, const V3 start, const V3 inv_dir, float ray_min, float ray_max,
                                          float &t_entry)
 {
+#ifndef RT_PLAIN_BOX_TEST
+    // x and y of either corner go through the packed subtract and multiply (two lanes' worth per instruction)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 s_xy = {start.x, start.y}, i_xy = {inv_dir.x, inv_dir.y};
+    const f32x2 lo_xy = {b.s0, b.s1}, hi_xy = {b.s4, b.s5};
+    const f32x2 p1 = (lo_xy - s_xy) * i_xy, p2 = (hi_xy - s_xy) * i_xy;
+    const V3 pos1 = v3(p1.x, p1.y, (b.s2 - start.z) * inv_dir.z);
+    const V3 pos2 = v3(p2.x, p2.y, (b.s6 - start.z) * inv_dir.z);
+#else
     const V3 pos1 = (v3(b.s0, b.s1, b.s2) - start) * inv_dir;
     const V3 pos2 = (v3(b.s4, b.s5, b.s6) - start) * inv_dir;
+#endif
     const float t_min = fmaxf(fmaxf(fminf(pos1.x, pos2.x), fminf(pos1.y, pos2.y)), fminf(pos1.z, pos2.z));
     const float t_max = fminf(fminf(fmaxf(pos1.x, pos2.x), fmaxf(pos1.y, pos2.y)), fmaxf(pos1.z, pos2.z));
     t_entry = fmaxf(t_min, ray_min);
