@@ -123,7 +123,7 @@ struct Placement {
     const GroupMove *move;        // per group: first sorted position inside its block of groups, parked count, offsets inside the block
     const uint2 *block_sums;      // per block of kGroupThreads groups: whole-warp and parked rays of the blocks before
     const uint32_t *block_main;   // ... and their sorted entries
-    uint32_t count, group_blocks, tile_blocks;
+    uint32_t count, group_blocks, tile_blocks, groups;
 };
 
 __device__ __forceinline__ uint32_t placed(const Placement &pl, uint32_t key, uint32_t index, uint32_t old_count, uint32_t all_aligned)
@@ -323,93 +323,91 @@ void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pai
     else sort_passes<kTile, kSortThreads>(stream, ws, in, out, count, n_dev, bits, passes, true);
 }
 
-// ---------------------------------------------------------------- sort + compaction in one sequence (free schedule)
+// ---------------------------------------------------------------- grouping + compaction in one sequence (free schedule)
 //
 // The reference sorts (three launches per pass), then finds the group boundaries in the sorted list,
 // scans the groups and moves every pair a second time (count_groups, update_groups, set_ray_index).
-// With the order free, the group sizes do not have to wait for the sort: one read of the new keys gives
-// the per-group histogram together with the first pass's tile counts, the group scan runs before the
-// scatter passes, and the final pass writes every pair straight to its re-packed place.  Five launches
-// (histogram, groups + digit scan, scatter, count + scan, final scatter) instead of eight.
+// With the order free, only the grouping matters, and no pair has to move twice: one read of the new keys
+// counts the groups and gives every pair a rank inside its group (k_fused_rank), the group scan turns the
+// counts into places (k_fused_groups), and every pair goes straight to its re-packed place (k_fused_place).
+// Three launches instead of eight.  The order of the pairs inside a group depends on the order in which
+// workgroups reach the group's counter, i.e. it may differ from run to run; which sample a finished slot
+// starts next follows from it, what any sample computes does not.
 
-constexpr uint32_t kHistSlices = 4;  // copies of the group histogram, so that a big group's counter takes a quarter of the atomics
-
-// Per-group histogram of the first n keys, one small tile per workgroup: counted in LDS, then one atomic
-// per non-empty group into the workgroup's slice of the global histogram.  The tile's digit counts for
-// the first pass are sums of its group counts.  s_mem: [groups][256 digits].
-__global__ __launch_bounds__(kSmallThreads) void k_fused_hist(const rt_index_pair *src, DevGlobal *glob, uint32_t *ghist,
-                                                              uint32_t *counts, uint32_t stride, uint32_t groups, uint32_t mask0)
+// Rank of every one of the first n pairs inside its group, one small tile per workgroup: the tile's pairs are
+// counted per group in LDS, handing each its rank among the tile's pairs of that group; one atomic per
+// non-empty group then reserves the tile's range in the group and returns where it starts.  s_group: [groups].
+__global__ __launch_bounds__(kSmallThreads) void k_fused_rank(const rt_index_pair *src, DevGlobal *glob, uint32_t *ghist,
+                                                              uint32_t *rank, uint32_t groups)
 {
-    extern __shared__ uint32_t s_mem[];
-    uint32_t *s_group = s_mem, *s_digit = s_mem + groups;
+    extern __shared__ uint32_t s_group[];
     constexpr uint32_t kPerThread = kSmallTile / kSmallThreads;
-    const uint32_t tid = threadIdx.x, base = blockIdx.x * kSmallTile, n = glob->g.ray_count;
-    if (blockIdx.x == 0 && tid == 0) glob->sort_count = n;  // the passes run after the live count has been replaced
+    const uint32_t tid = threadIdx.x, lane = tid & 63, base = blockIdx.x * kSmallTile, n = glob->g.ray_count;
+    if (blockIdx.x == 0 && tid == 0) glob->sort_count = n;  // the later kernels run after the live count has been replaced
     if (base >= n) return;
-    uint32_t keys[kPerThread];
+    uint32_t keys[kPerThread], local[kPerThread];
 #pragma unroll
     for (uint32_t i = 0; i < kPerThread; i++) {
         const uint32_t p = base + i * kSmallThreads + tid;
         keys[i] = p < n ? src[p].key : 0xFFFFFFFFu;
     }
-    for (uint32_t i = tid; i < groups + kRadix; i += kSmallThreads) s_mem[i] = 0;
+    for (uint32_t i = tid; i < groups; i += kSmallThreads) s_group[i] = 0;
     __syncthreads();
+    const unsigned long long lanes_below = (1ull << lane) - 1;
 #pragma unroll
     for (uint32_t i = 0; i < kPerThread; i++) {
         bool todo = base + i * kSmallThreads + tid < n;
         uint32_t id = keys[i] & kIdMask;
         id = id < groups ? id : groups - 1;
+        keys[i] = id;
+        local[i] = 0;
         // Neighbouring rays mostly move on to the same few nodes; 64 LDS atomics on one word would run one
-        // after the other.  The two most likely values are counted with a ballot each, the rest one by one.
+        // after the other.  The two most likely values take one atomic per wave each, the rest one per lane.
 #pragma unroll
         for (int round = 0; round < 2; round++) {
             const unsigned long long left = __ballot(todo);
             if (!left) break;
             const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)id, (int)(__ffsll((long long)left) - 1));
             const unsigned long long same = __ballot(todo && id == first);
+            const uint32_t leader = (uint32_t)(__ffsll((long long)same) - 1);
+            uint32_t before = 0;
+            if (todo && id == first && lane == leader) before = atomicAdd(&s_group[first], (uint32_t)__popcll(same));
+            before = (uint32_t)__builtin_amdgcn_readlane((int)before, (int)leader);
             if (todo && id == first) {
                 todo = false;
-                if ((tid & 63) == (uint32_t)(__ffsll((long long)same) - 1)) atomicAdd(&s_group[first], (uint32_t)__popcll(same));
+                local[i] = before + (uint32_t)__popcll(same & lanes_below);
             }
         }
-        if (todo) atomicAdd(&s_group[id], 1u);
+        if (todo) local[i] = atomicAdd(&s_group[id], 1u);
     }
     __syncthreads();
-    uint32_t *slice = ghist + (blockIdx.x % kHistSlices) * groups;
     for (uint32_t g = tid; g < groups; g += kSmallThreads) {
         const uint32_t c = s_group[g];
-        if (c) {
-            atomicAdd(&slice[g], c);
-            atomicAdd(&s_digit[g & mask0], c);
-        }
+        if (c) s_group[g] = atomicAdd(&ghist[g], c);
     }
     __syncthreads();
-    for (uint32_t d = tid; d < kRadix; d += kSmallThreads) counts[d * stride + blockIdx.x] = s_digit[d];
+#pragma unroll
+    for (uint32_t i = 0; i < kPerThread; i++) {
+        const uint32_t p = base + i * kSmallThreads + tid;
+        if (p < n) rank[p] = local[i] + s_group[keys[i]];
+    }
 }
 
 // update_groups (ray-tracer.cl:255-290) from the histogram: one thread per group, block-wide prefix sums,
-// the last block to finish scans the block totals and updates the frame counters.  The workgroups
-// beyond the group blocks scan the first pass's tile counts, one digit each.
+// the last block to finish scans the block totals and updates the frame counters.
 __global__ __launch_bounds__(kGroupThreads) void k_fused_groups(DevGlobal *glob, rt_group_data *grp_data, uint32_t *ghist,
-                                                                 CompactWorkspace ws, uint32_t *block_main, uint32_t group_blocks,
-                                                                 uint32_t *counts, uint32_t *totals, uint32_t stride)
+                                                                 CompactWorkspace ws, uint32_t *block_main, uint32_t group_blocks)
 {
     __shared__ uint32_t s_wave[kGroupThreads / 64];
     __shared__ bool s_last;
     const uint32_t tid = threadIdx.x;
-    if (blockIdx.x >= group_blocks) {
-        scan_digit_row(counts, totals, glob->sort_count, stride, kSmallTile, blockIdx.x - group_blocks, s_wave);
-        return;
-    }
     const uint32_t g = blockIdx.x * kGroupThreads + tid;
     const uint32_t groups = glob->g.group_count, n = glob->sort_count;
     uint32_t main_count = 0, aligned = 0, tail = 0;
     rt_group_data grp = rt_group_data{{0, 0}, {0, 0}, {0, 0}};
     if (g < groups) {
-        for (uint32_t k = 0; k < kHistSlices; k++) {
-            main_count += ghist[k * groups + g];
-            ghist[k * groups + g] = 0;  // ready for the next step
-        }
+        main_count = ghist[g];
+        ghist[g] = 0;  // ready for the next step
         grp = grp_data[g];
         const uint32_t total = main_count + grp.count[1];
         tail = g != groups - 1 ? total % glob->warp_width : total;  // the last group is the dead-ray bin
@@ -459,50 +457,72 @@ __global__ __launch_bounds__(kGroupThreads) void k_fused_groups(DevGlobal *glob,
     }
 }
 
-uint32_t fused_hist_slices() { return kHistSlices; }
+// set_ray_index (ray-tracer.cl:293-302): every pair to its place in the re-packed index -- the whole warps of
+// all groups first, group by group, then the parked remainders.  A pair of the first n goes by its rank among
+// its group's new pairs, a pair parked earlier by its place among the parked ones, which follow the new ones.
+// The first workgroups also finish the group table (ray-tracer.cl:262-289).
+__global__ __launch_bounds__(kGroupThreads) void k_fused_place(const rt_index_pair *src, const uint32_t *rank, rt_index_pair *dst,
+                                                                Placement pl)
+{
+    const uint32_t old_count = pl.glob->g.old_count, all_aligned = pl.glob->g.ray_count;
+    if (blockIdx.x < pl.group_blocks) {
+        const uint32_t g = blockIdx.x * kGroupThreads + threadIdx.x;
+        if (g < pl.glob->g.group_count) {
+            const GroupMove m = pl.move[g];
+            const uint2 block = pl.block_sums[blockIdx.x];
+            pl.grp_data[g].base[0] = pl.block_main[blockIdx.x] + m.base0;
+            *reinterpret_cast<uint2 *>(pl.grp_data[g].offset) = make_uint2(block.x + m.off0, all_aligned + block.y + m.off1);
+        }
+    }
+    if (blockIdx.x >= pl.tile_blocks) return;
+    constexpr uint32_t kPerThread = kSmallTile / kGroupThreads;
+    const uint32_t base = blockIdx.x * kSmallTile;
+    rt_index_pair e[kPerThread];
+    uint32_t r[kPerThread];
+#pragma unroll
+    for (uint32_t i = 0; i < kPerThread; i++) {
+        const uint32_t p = base + i * kGroupThreads + threadIdx.x;
+        e[i] = src[p];
+        r[i] = p < old_count ? rank[p] : 0u;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kPerThread; i++) {
+        const uint32_t p = base + i * kGroupThreads + threadIdx.x;
+        uint32_t g = e[i].key & kIdMask;
+        if (p < old_count && g >= pl.groups) g = pl.groups - 1;  // (as counted)
+        const GroupMove m = pl.move[g];
+        const uint2 block = pl.block_sums[g / kGroupThreads];
+        const uint32_t index = p < old_count ? r[i] : p - m.base1;  // place among the group's pairs, new ones first
+        const uint32_t to = index < m.count1 ? index + all_aligned + block.y + m.off1 : index + block.x + m.off0 - m.count1;
+        if (to < pl.count) dst[to] = e[i];  // always true for consistent group data; keeps bad caller data from faulting
+    }
+}
+
+uint32_t fused_hist_slices() { return 1; }
 
 uint32_t fused_hist_lds_bytes(uint32_t group_count)
 {
-    return (group_count + kRadix) * sizeof(uint32_t);
+    return group_count * sizeof(uint32_t);
 }
 
 hipError_t fused_setup(uint32_t group_count)
 {
     const uint32_t bytes = fused_hist_lds_bytes(group_count);
     if (bytes <= 48 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_rank), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 void launch_fused(hipStream_t stream, const SortWorkspace &ws, const FusedWorkspace &fw, const CompactWorkspace &cw, DevGlobal *glob,
                   rt_group_data *grp_data, const rt_index_pair *in, rt_index_pair *out, uint32_t count, uint32_t group_count)
 {
-    uint32_t bits = 0;
-    while (bits < 24 && ((group_count - 1) >> bits)) bits++;
-    if (bits == 0) bits = 1;
-    const uint32_t passes = (bits + kRadixBits - 1) / kRadixBits;  // 1 or 2: the fused path is for at most kFusedMaxGroups groups
-    const uint32_t digit_bits = (bits + passes - 1) / passes;
-    const uint32_t mask0 = (1u << digit_bits) - 1;
-    const uint32_t tiles = count / kSmallTile, stride = ws.tiles * kSortCountsPerTile;
+    const uint32_t tiles = count / kSmallTile;
     const uint32_t group_blocks = compact_group_blocks(group_count);
-    const uint32_t *n_dev = &glob->sort_count;
-    const Placement pl{glob, grp_data, cw.move, cw.block_sums, fw.block_main, count, group_blocks, tiles};
-    const uint32_t final_grid = tiles > group_blocks ? tiles : group_blocks;
-
-    k_fused_hist<<<tiles, kSmallThreads, fused_hist_lds_bytes(group_count), stream>>>(in, glob, fw.ghist, ws.counts, stride, group_count, mask0);
-    k_fused_groups<<<group_blocks + mask0 + 1, kGroupThreads, 0, stream>>>(glob, grp_data, fw.ghist, cw, fw.block_main, group_blocks,
-                                                                          ws.counts, ws.totals, stride);
-    if (passes == 1) {
-        k_sort_scatter<kSmallTile, kSmallThreads, true><<<final_grid, kSmallThreads, 0, stream>>>(in, out, in, n_dev, ws.counts, ws.totals, stride,
-                                                                                                 0, mask0, 0u, pl);
-        return;
-    }
-    k_sort_scatter<kSmallTile, kSmallThreads, false><<<tiles, kSmallThreads, 0, stream>>>(in, ws.tmp, nullptr, n_dev, ws.counts, ws.totals, stride, 0,
-                                                                                         mask0, 0u, Placement{});
-    const uint32_t mask1 = (1u << (bits - digit_bits)) - 1;
-    k_sort_count<kSmallTile, kSmallThreads><<<tiles, kSmallThreads, 0, stream>>>(ws.tmp, n_dev, ws.counts, stride, digit_bits, mask1);
-    k_sort_scan<<<mask1 + 1, 256, 0, stream>>>(ws.counts, ws.totals, n_dev, stride, kSmallTile);
-    k_sort_scatter<kSmallTile, kSmallThreads, true><<<final_grid, kSmallThreads, 0, stream>>>(ws.tmp, out, in, n_dev, ws.counts, ws.totals, stride,
-                                                                                             digit_bits, mask1, 0u, pl);
+    uint32_t *rank = reinterpret_cast<uint32_t *>(ws.tmp);  // one word per pair in the sort's ping-pong buffer
+    const Placement pl{glob, grp_data, cw.move, cw.block_sums, fw.block_main, count, group_blocks, tiles, group_count};
+    const uint32_t place_grid = tiles > group_blocks ? tiles : group_blocks;
+    k_fused_rank<<<tiles, kSmallThreads, fused_hist_lds_bytes(group_count), stream>>>(in, glob, fw.ghist, rank, group_count);
+    k_fused_groups<<<group_blocks, kGroupThreads, 0, stream>>>(glob, grp_data, fw.ghist, cw, fw.block_main, group_blocks);
+    k_fused_place<<<place_grid, kGroupThreads, 0, stream>>>(in, rank, out, pl);
 }
 
 }  // namespace rtd
