@@ -127,11 +127,15 @@ typedef struct {
  * through the hierarchy depends only on its own state and the scene (process, ray-tracer.cl:119-232),
  * so every sample's result -- its hit record and what it adds to its pixel -- is the same as with the
  * reference's schedule; what differs is which slot holds which sample after a given step, i.e.
- * rt_dump_state no longer equals the reference's buffers step by step.  With the flag set the sort
- * keeps equal keys in their plain order instead of the reference's thread-major tile order
- * (sort.cl:26-27), sky/light/material shaders run inside the kernel that empties a ray's queue instead
- * of as a step of their own, and a finished slot is re-initialised and sent through the scene root in one
- * launch.  Without it (0) every step reproduces the reference's make_step exactly. */
+ * rt_dump_state no longer equals the reference's buffers step by step.  With the flag set the rays are
+ * grouped by key rather than sorted (the order inside a group is not defined and may differ between runs:
+ * it decides which sample a finished slot starts next, and with it the order in which a pixel's samples are
+ * added up), sky/light/material shaders run inside the kernel that empties a ray's queue instead of as a
+ * step of their own, a finished slot is re-initialised and sent through the scene root in one launch, and
+ * the ray slots keep only what the kernels read: rt_dump_state shows a ray's live queue entries (those
+ * behind queue_len as zeros; entries beyond the last hit may still be listed), stale `orig` fields, and
+ * the weight of a camera ray that has not bounced is implied (1).  Without the flag (0) every step
+ * reproduces the reference's make_step exactly. */
 #define RT_FLAG_FREE_SCHEDULE 1u
 
 /* Shading beyond the reference's one shadow ray per sample, also in rt_config.flags: bits 8-11 say what a
@@ -215,8 +219,9 @@ int rt_get_counters(rt_ctx *ctx, rt_counters *dst);
  * input block-wise in thread-major order as local_count does (sort.cl:26-27), and copies pairs
  * [n, count) through.  in/out are host pointers, or device pointers when on_device != 0; they must
  * not overlap.  count must be a multiple of RT_SORT_TILE and at most the context's pool size.
- * On a context created with RT_FLAG_FREE_SCHEDULE the sort is the one that context's steps use: stable
- * over the plain order of the first n pairs, by the bits of group_count - 1. */
+ * On a context created with RT_FLAG_FREE_SCHEDULE the sort is stable over the plain order of the first n
+ * pairs, by the bits of group_count - 1 (what such a context's steps use for more than 32,768 groups; with
+ * fewer they group the pairs without sorting them). */
 int rt_sort_pairs(rt_ctx *ctx, const rt_index_pair *in, rt_index_pair *out,
                   uint32_t count, uint32_t n, uint32_t group_count, int on_device);
 

@@ -46,12 +46,13 @@ void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pai
                  uint32_t count, const uint32_t *n_dev, uint32_t group_count, bool plain_order = false);
 uint32_t sort_key_bits(uint32_t group_count);
 
-// Sort + queue compaction of the free schedule as one sequence (rt_sort.hip): per-group histogram, group
-// scan, scatter passes, the last of which writes the re-packed index.  For at most kFusedMaxGroups groups.
+// Grouping + queue compaction of the free schedule as one sequence (rt_sort.hip): per-group histogram that also
+// ranks every pair inside its group, group scan, one placement of every pair in the re-packed index; ws.tmp holds
+// the ranks.  For at most kFusedMaxGroups groups.
 constexpr uint32_t kFusedMaxGroups = 32768;  // the histogram of a workgroup lives in LDS
 struct FusedWorkspace {
-    uint32_t *ghist;       // [fused_hist_slices()][group_count] entries per group, zero between steps
-    uint32_t *block_main;  // [blocks of kGroupThreads groups] sorted entries per block, then their exclusive prefix sums
+    uint32_t *ghist;       // [group_count] new pairs per group, zero between steps
+    uint32_t *block_main;  // [blocks of kGroupThreads groups] new pairs per block, then their exclusive prefix sums
 };
 uint32_t fused_hist_slices();
 hipError_t fused_setup(uint32_t group_count);  // once per scene, before the first launch_fused

@@ -115,50 +115,13 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *counts, uint32_t *t
 
 // Scatter of one pass.  first_pass: read the tile in the reference's thread-major order.
 // tail_src (final pass only): where pairs at or beyond n are copied from.
-// What the final pass of the fused sort + compaction needs to send every pair straight to its place in
-// the re-packed index (set_ray_index, ray-tracer.cl:293-302) instead of to its sorted position.
-struct Placement {
-    const DevGlobal *glob;
-    rt_group_data *grp_data;
-    const GroupMove *move;        // per group: first sorted position inside its block of groups, parked count, offsets inside the block
-    const uint2 *block_sums;      // per block of kGroupThreads groups: whole-warp and parked rays of the blocks before
-    const uint32_t *block_main;   // ... and their sorted entries
-    uint32_t count, group_blocks, tile_blocks, groups;
-};
-
-__device__ __forceinline__ uint32_t placed(const Placement &pl, uint32_t key, uint32_t index, uint32_t old_count, uint32_t all_aligned)
-{
-    const uint32_t g = key & kIdMask;
-    const GroupMove m = pl.move[g];
-    const uint2 block = pl.block_sums[g / kGroupThreads];
-    // position among the group's entries: new ones first, then the ones parked before (ray-tracer.cl:297-298)
-    index -= index < old_count ? pl.block_main[g / kGroupThreads] + m.base0 : m.base1;
-    return index < m.count1 ? index + all_aligned + block.y + m.off1 : index + block.x + m.off0 - m.count1;
-}
-
-template <uint32_t TILE, uint32_t THREADS, bool COMPACT>
+template <uint32_t TILE, uint32_t THREADS>
 __global__ __launch_bounds__(THREADS) void k_sort_scatter(const rt_index_pair *src, rt_index_pair *dst,
                                                           const rt_index_pair *tail_src, const uint32_t *n_ptr,
                                                           const uint32_t *counts, const uint32_t *totals,
                                                           uint32_t tiles, uint32_t shift, uint32_t mask,
-                                                          uint32_t first_pass, Placement pl)
+                                                          uint32_t first_pass)
 {
-    uint32_t old_count = 0, all_aligned = 0;
-    if (COMPACT) {
-        static_assert(!COMPACT || THREADS == kGroupThreads, "one thread per group of a block");
-        old_count = pl.glob->g.old_count;
-        all_aligned = pl.glob->g.ray_count;
-        if (blockIdx.x < pl.group_blocks) {  // finished entries of this block's groups (ray-tracer.cl:262-289)
-            const uint32_t g = blockIdx.x * kGroupThreads + threadIdx.x;
-            if (g < pl.glob->g.group_count) {
-                const GroupMove m = pl.move[g];
-                const uint2 block = pl.block_sums[blockIdx.x];
-                pl.grp_data[g].base[0] = pl.block_main[blockIdx.x] + m.base0;
-                *reinterpret_cast<uint2 *>(pl.grp_data[g].offset) = make_uint2(block.x + m.off0, all_aligned + block.y + m.off1);
-            }
-        }
-        if (blockIdx.x >= pl.tile_blocks) return;
-    }
     constexpr uint32_t kTile = TILE, kSortThreads = THREADS, kSortWaves = THREADS / 64, kPerThread = TILE / THREADS;
     // The tile, one padding slot after every 16 pairs: the transposing store (stride 16 pairs per
     // thread) and the linear 8-byte reads are then both free of bank conflicts.
@@ -177,13 +140,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const rt_index_pair *s
         for (uint32_t i = 0; i < kPerThread; i++) {
             const uint32_t p = i * kSortThreads + tid;
             if (p >= m) {
-                const rt_index_pair e = tail_src[base + p];
-                if (COMPACT) {
-                    const uint32_t at = placed(pl, e.key, base + p, old_count, all_aligned);
-                    if (at < pl.count) dst[at] = e;  // always true for consistent group data
-                } else {
-                    dst[base + p] = e;
-                }
+                dst[base + p] = tail_src[base + p];
             }
         }
     }
@@ -268,13 +225,7 @@ __global__ __launch_bounds__(THREADS) void k_sort_scatter(const rt_index_pair *s
         const uint32_t j = i * kSortThreads + tid;
         if (j < m) {
             const uint2 e = s_tile[j];
-            const uint32_t at = s_gbase[(e.x >> shift) & mask] + j;
-            if (COMPACT) {
-                const uint32_t to = placed(pl, e.x, at, old_count, all_aligned);
-                if (to < pl.count) dst[to] = rt_index_pair{e.x, e.y};
-            } else {
-                dst[at] = rt_index_pair{e.x, e.y};
-            }
+            dst[s_gbase[(e.x >> shift) & mask] + j] = rt_index_pair{e.x, e.y};
         }
     }
 }
@@ -300,8 +251,8 @@ static void sort_passes(hipStream_t stream, const SortWorkspace &ws, const rt_in
         rt_index_pair *dst = ((passes - 1 - k) % 2 == 0) ? out : ws.tmp;
         k_sort_count<TILE, THREADS><<<tiles, THREADS, 0, stream>>>(src, n_dev, ws.counts, stride, shift, mask);
         k_sort_scan<<<mask + 1, 256, 0, stream>>>(ws.counts, ws.totals, n_dev, stride, TILE);
-        k_sort_scatter<TILE, THREADS, false><<<tiles, THREADS, 0, stream>>>(src, dst, final_pass ? in : nullptr, n_dev, ws.counts, ws.totals,
-                                                                            stride, shift, mask, k == 0 && thread_major ? 1u : 0u, Placement{});
+        k_sort_scatter<TILE, THREADS><<<tiles, THREADS, 0, stream>>>(src, dst, final_pass ? in : nullptr, n_dev, ws.counts, ws.totals,
+                                                                     stride, shift, mask, k == 0 && thread_major ? 1u : 0u);
         src = dst;
     }
 }
@@ -333,6 +284,16 @@ void launch_sort(hipStream_t stream, const SortWorkspace &ws, const rt_index_pai
 // Three launches instead of eight.  The order of the pairs inside a group depends on the order in which
 // workgroups reach the group's counter, i.e. it may differ from run to run; which sample a finished slot
 // starts next follows from it, what any sample computes does not.
+
+// What k_fused_place needs to send a pair to its place in the re-packed index.
+struct Placement {
+    const DevGlobal *glob;
+    rt_group_data *grp_data;
+    const GroupMove *move;        // per group: first place inside its block of groups, parked count, offsets inside the block
+    const uint2 *block_sums;      // per block of kGroupThreads groups: whole-warp and parked rays of the blocks before
+    const uint32_t *block_main;   // ... and their new pairs
+    uint32_t count, group_blocks, tile_blocks, groups;
+};
 
 // Rank of every one of the first n pairs inside its group, one small tile per workgroup: the tile's pairs are
 // counted per group in LDS, handing each its rank among the tile's pairs of that group; one atomic per
