@@ -627,6 +627,17 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     RT_HIP(c, hipMemcpy(c->cluster, dev_clusters.data(), sizeof(ClusterRecord) * dev_clusters.size(), hipMemcpyHostToDevice));
     if (n_vtx) RT_HIP(c, hipMemcpy(c->vtx, vtx, sizeof(rt_vertex) * n_vtx, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->tri, dev_tri.data(), sizeof(uint32_t) * dev_tri.size(), hipMemcpyHostToDevice));
+    // The leaf kernel tests triangles two at a time with both triangles' values side by side: records 2k and
+    // 2k + 1 (leaves start on even indices and are filled up to even counts) are interleaved value by value.
+    for (size_t k = 0; k + 1 < dev_rec.size(); k += 2) {
+        float both[2][12], mixed[24];
+        std::memcpy(both, &dev_rec[k], sizeof(both));
+        for (int v = 0; v < 12; v++) {
+            mixed[2 * v] = both[0][v];
+            mixed[2 * v + 1] = both[1][v];
+        }
+        std::memcpy(&dev_rec[k], mixed, sizeof(mixed));
+    }
     RT_HIP(c, hipMemcpy(c->tri_rec, dev_rec.data(), sizeof(TriRecord) * dev_rec.size(), hipMemcpyHostToDevice));
 
     DevGlobal init;

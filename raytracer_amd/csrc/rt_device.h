@@ -51,7 +51,8 @@ static_assert(sizeof(RaySlot) == 256, "ray slot must be 256 bytes");
 
 // Triangle of a leaf, expanded when the scene is uploaded: first corner, two edges and their cross
 // product (the values mesh_shader derives per triangle, shader.cl:126-127), 48 bytes, fetched with
-// scalar loads because every lane of a wave is in the same leaf.
+// scalar loads because every lane of a wave is in the same leaf.  On the device the records of triangles
+// 2k and 2k + 1 are interleaved value by value (r0.x of both, r0.y of both, ...): see visit_mesh.
 struct alignas(16) TriRecord {
     float r0[3], p[3], q[3], n[3];
 };
@@ -143,6 +144,30 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b)
 {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+// Two floats in a register pair: subtract, add, multiply and fused multiply-add work on both at once (v_pk_*_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
+
+// 1.0f / w for both halves, correctly rounded: the sequence the compiler emits for one float division (scale,
+// estimate, one Newton step, three residual corrections, un-scale, special cases), with the six multiply-adds of
+// its core done for both halves at once.  Same bits as 1.0f / w.x and 1.0f / w.y for every float
+// (tools/micro/rcp_exact.hip runs all 2^32 of them).
+__device__ __forceinline__ f32x2 reciprocal2(f32x2 w)
+{
+    bool unused0, unused1, scaled0, scaled1;
+    const f32x2 d = {__builtin_amdgcn_div_scalef(1.0f, w.x, false, &unused0), __builtin_amdgcn_div_scalef(1.0f, w.y, false, &unused1)};
+    const f32x2 n = {__builtin_amdgcn_div_scalef(1.0f, w.x, true, &scaled0), __builtin_amdgcn_div_scalef(1.0f, w.y, true, &scaled1)};
+    const f32x2 y0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f32x2 e = __builtin_elementwise_fma(-d, y0, splat(1.0f));
+    const f32x2 y1 = __builtin_elementwise_fma(e, y0, y0);
+    const f32x2 q0 = n * y1;
+    const f32x2 r0 = __builtin_elementwise_fma(-d, q0, n);
+    const f32x2 q1 = __builtin_elementwise_fma(r0, y1, q0);
+    const f32x2 r1 = __builtin_elementwise_fma(-d, q1, n);
+    return f32x2{__builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(r1.x, y1.x, q1.x, scaled0), w.x, 1.0f),
+                 __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(r1.y, y1.y, q1.y, scaled1), w.y, 1.0f)};
+}
+
 // The fields of a slot every visit reads, in registers: bytes 0-47 of the slot, three 16-byte requests.
 struct HotRay {
     uint32_t pixel, sample_id, material_id;

@@ -425,10 +425,12 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     const LocalRay lr = make_local(g, h, head.local0, a.scene.mat);
 
     count_lanes(a.frame, kTriTests, true, grp.z);
-    // Triangle scan.  Leaf payload is wave-uniform: 48 bytes per triangle (r0, p, q, n) through the
-    // scalar cache, two triangles (three 32-byte loads) at a time; the device copy of a leaf's list
-    // starts on an even index, is filled up to an even count with null triangles and is followed by
-    // readable entries, so the next pair is always requested before the current pair is tested.
+    // Triangle scan.  Leaf payload is wave-uniform and comes through the scalar cache, two triangles at a time:
+    // a pair's record is 96 bytes, the twelve values of the two triangles (r0, p, q, n) interleaved, so that each
+    // value of the first triangle shares an aligned register pair with the same value of the second and the
+    // subtractions, products and sums of the test run for both triangles at once (packed FP32).  The device copy
+    // of a leaf's list starts on an even index, is filled up to an even count with null triangles and is followed
+    // by readable entries, so the next pair is always requested before the current pair is tested.
     ConstPtr<f32x8> rec = const_ptr<f32x8>(a.scene.tri_rec + grp.y);
 #if defined(RT_STAMPS) && RT_STAMPS == 2
     asm volatile("" ::"v"(lr.start.x), "v"(lr.dir.x), "v"(lr.tmin));
@@ -437,23 +439,35 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     float best = lr.tmax, hit_u = 0, hit_v = 0;
     uint32_t hit_index = 0xFFFFFFFFu;
     const uint32_t count = grp.z;
-    auto test_tri = [&](V3 r0, V3 p, V3 q_, V3 n, uint32_t i) {
-        const V3 r = r0 - lr.start;
-        float w = dot(lr.dir, n);
-        w = 1 / w;
-        const float tt = dot(r, n) * w;
-        if (!(tt > lr.tmin && tt < best)) return;
-        const V3 dr = cross(lr.dir, r);
-        const float u = -dot(q_, dr) * w, v = dot(p, dr) * w;
-        if (!(u >= 0 && v >= 0 && u + v <= 1)) return;
-        best = tt;
-        hit_u = u;
-        hit_v = v;
-        hit_index = i;
-    };
+    const f32x2 sx = splat(lr.start.x), sy = splat(lr.start.y), sz = splat(lr.start.z);
+    const f32x2 dx = splat(lr.dir.x), dy = splat(lr.dir.y), dz = splat(lr.dir.z);
+    // mesh_shader's test (shader.cl:126-136) for triangles i and i + 1: every operation as there, in the same
+    // order; the first triangle's hit is committed before the second is looked at.
     auto test_two = [&](const f32x8 x, const f32x8 y, const f32x8 z, uint32_t i) {
-        test_tri(v3(x.s0, x.s1, x.s2), v3(x.s3, x.s4, x.s5), v3(x.s6, x.s7, y.s0), v3(y.s1, y.s2, y.s3), i);
-        test_tri(v3(y.s4, y.s5, y.s6), v3(y.s7, z.s0, z.s1), v3(z.s2, z.s3, z.s4), v3(z.s5, z.s6, z.s7), i + 1);
+        const f32x2 r0x = {x.s0, x.s1}, r0y = {x.s2, x.s3}, r0z = {x.s4, x.s5};
+        const f32x2 nx = {z.s2, z.s3}, ny = {z.s4, z.s5}, nz = {z.s6, z.s7};
+        const f32x2 rx = r0x - sx, ry = r0y - sy, rz = r0z - sz;
+        const f32x2 w = reciprocal2((dx * nx + dy * ny) + dz * nz);
+        const f32x2 tt = ((rx * nx + ry * ny) + rz * nz) * w;
+        const bool near0 = tt.x > lr.tmin && tt.x < best, near1 = tt.y > lr.tmin && tt.y < best;
+        if (!(near0 || near1)) return;
+        const f32x2 px = {x.s6, x.s7}, py = {y.s0, y.s1}, pz = {y.s2, y.s3};
+        const f32x2 qx = {y.s4, y.s5}, qy = {y.s6, y.s7}, qz = {z.s0, z.s1};
+        const f32x2 cx = dy * rz - dz * ry, cy = dz * rx - dx * rz, cz = dx * ry - dy * rx;  // cross(dir, r)
+        const f32x2 u = -((qx * cx + qy * cy) + qz * cz) * w, v = ((px * cx + py * cy) + pz * cz) * w;
+        const f32x2 uv = u + v;
+        if (near0 && u.x >= 0 && v.x >= 0 && uv.x <= 1) {
+            best = tt.x;
+            hit_u = u.x;
+            hit_v = v.x;
+            hit_index = i;
+        }
+        if (near1 && tt.y < best && u.y >= 0 && v.y >= 0 && uv.y <= 1) {
+            best = tt.y;
+            hit_u = u.y;
+            hit_v = v.y;
+            hit_index = i + 1;
+        }
     };
     if (count) {
         f32x8 a0 = rec[0], a1 = rec[1], a2 = rec[2];
