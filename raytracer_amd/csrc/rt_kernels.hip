@@ -119,6 +119,22 @@ __device__ __forceinline__ HotRay camera_ray(const rt_camera &cam, const DevGlob
     return h;
 }
 
+// Which of the samples [first, first + count) the finished slot at position `index` of the re-packed index starts
+// (free schedule).  The reference hands them out in index order (first + index, ray-tracer.cl:149), which puts 64
+// pixels of one image row into a wave.  Here every aligned run of eight image rows inside the range is handed out
+// in blocks of 8 x 8 pixels instead: a wave's rays stay close together on their way down the hierarchy, so
+// fewer of a box list's clusters are entered by some lane of the wave.  A permutation of the range: every sample is
+// started exactly once either way, and what a sample computes does not depend on the slot that runs it.
+__device__ __forceinline__ uint32_t blocked_sample(const rt_camera &cam, uint32_t first, uint32_t count, uint32_t index)
+{
+    const uint32_t sample = first + index, width = cam.width, chunk = 8 * width;
+    if (width % 8 || index >= count) return sample;
+    const uint32_t start = sample / chunk * chunk;  // the run of eight rows this sample lies in, if whole and inside the range
+    if (start < first || start + chunk > first + count || start + chunk < start) return sample;
+    const uint32_t t = sample - start, block = t / 64, lane = t % 64;
+    return start + (lane / 8) * width + 8 * block + lane % 8;
+}
+
 // init_ray (ray-tracer.cl:56-74).  Sample ids at or beyond the limit take the dead-ray exit the
 // reference left commented out (ray-tracer.cl:61): the slot is left alone and parked in the last group.
 // LEAN: `root` is not stored again -- every slot of the pool got the camera's root when the frame was
@@ -1110,7 +1126,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
     uint32_t sample = 0;
     if (FREE) {
         if (key == RT_SPAWN_GROUP) {  // a finished slot: the next sample starts here and visits the root below
-            sample = index + glob->g.pixel_offset;
+            sample = blocked_sample(a.cam, glob->g.pixel_offset, glob->g.pixel_count, index);
             const uint32_t limit = glob->sample_limit;
             fresh = !(limit && sample >= limit);
             count_lanes(a.frame, kPrimarySpawned, fresh);
