@@ -342,9 +342,23 @@ __global__ __launch_bounds__(kSmallThreads) void k_fused_rank(const rt_index_pai
         if (todo) local[i] = atomicAdd(&s_group[id], 1u);
     }
     __syncthreads();
-    for (uint32_t g = tid; g < groups; g += kSmallThreads) {
-        const uint32_t c = s_group[g];
-        if (c) s_group[g] = atomicAdd(&ghist[g], c);
+    // (eight reservations in flight per thread: one after the other they would take a memory round trip each)
+    constexpr uint32_t kBatch = 8;
+    for (uint32_t first = tid; first < groups; first += kBatch * kSmallThreads) {
+        uint32_t c[kBatch], start[kBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; k++) {
+            const uint32_t g = first + k * kSmallThreads;
+            c[k] = g < groups ? s_group[g] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; k++) {
+            start[k] = 0;
+            if (c[k]) start[k] = atomicAdd(&ghist[first + k * kSmallThreads], c[k]);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; k++)
+            if (c[k]) s_group[first + k * kSmallThreads] = start[k];
     }
     __syncthreads();
 #pragma unroll
