@@ -425,6 +425,25 @@ __device__ __forceinline__ uint32_t run_end_group(uint32_t key, RaySlot *ray, co
     return mat_shader<true>(ray, color, a.frame.glob->shading);
 }
 
+// Asks for the 64-byte lines of a wave-uniform list ahead of the scan that reads it through the scalar path one
+// batch after the other: the wave's active lanes touch up to four lines each, all requests in flight together, so
+// that by the time the scan gets to a line it is in the L2 cache.  The sum of the touched words is returned and has
+// to be handed to touch_done() after the scan (that is what keeps the loads, and where they are waited for).
+__device__ __forceinline__ uint32_t touch_list(const void *list, uint32_t bytes)
+{
+    const unsigned long long active = __ballot(true);
+    const uint32_t workers = (uint32_t)__popcll(active), rank = (uint32_t)__popcll(active & ((1ull << lane_id()) - 1));
+    const char *base = static_cast<const char *>(list);
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t at = (rank + k * workers) * 64;
+        if (at < bytes) sum += *reinterpret_cast<const uint32_t *>(base + at);
+    }
+    return sum;
+}
+__device__ __forceinline__ void touch_done(uint32_t sum) { asm volatile("" ::"v"(sum)); }
+
 // ---------------------------------------------------------------- leaf visit (shader.cl:115-139, ray-tracer.cl:149-203)
 
 // LEAN (free schedule): `orig` is not kept up, and a ray whose queue has emptied is not given its end group
@@ -439,6 +458,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     const uint32_t queue_len = h.queue_len;
     const RayHit head = ray->queue[0];
     const LocalRay lr = make_local(g, h, head.local0, a.scene.mat);
+    const uint32_t touched = touch_list(a.scene.tri_rec + grp.y, (grp.z + 1) / 2 * (2 * (uint32_t)sizeof(TriRecord)));
 
     count_lanes(a.frame, kTriTests, true, grp.z);
     // Triangle scan.  Leaf payload is wave-uniform and comes through the scalar cache, two triangles at a time:
@@ -502,6 +522,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
         }
     }
 
+    touch_done(touched);
     MISC_STAMP(t_scanned);
     MISC_STAMP_ADD(a.frame, 0, t_start, t_loaded);
     MISC_STAMP_ADD(a.frame, 1, t_loaded, t_scanned);
