@@ -40,6 +40,7 @@ struct rt_ctx {
     hipGraphExec_t step_graph = nullptr;  // one step (both streams), captured on first use; dropped when its arguments change
     bool use_graph = true;
     bool free_schedule = false;  // RT_FLAG_FREE_SCHEDULE
+    bool long_lists = false;     // the uploaded scene has a box list of more than kMaxClusteredBoxes boxes
 
     rt_group *grp = nullptr;
     rt_matrix *mat = nullptr;
@@ -113,6 +114,7 @@ LaunchCtx launch_ctx(const rt_ctx *c)
     l.area_size = c->area_size;
     l.group_count = c->group_count;
     l.free_schedule = c->free_schedule;
+    l.long_lists = c->long_lists;
     return l;
 }
 
@@ -247,16 +249,23 @@ void split_spatially(const rt_aabb *boxes, std::vector<uint32_t> ids, std::vecto
     split_spatially(boxes, std::vector<uint32_t>(ids.begin() + half, ids.end()), out);
 }
 
-ClusterSet build_clusters(const rt_aabb *boxes, uint32_t count)
+// One cluster per eight consecutive boxes.
+ClusterSet run_clusters(const rt_aabb *boxes, uint32_t count)
 {
-    ClusterSet runs, spatial;
-    double cost_runs = 0, cost_spatial = 0;
+    ClusterSet runs;
     for (uint32_t first = 0; first < count; first += 8) {
         std::vector<uint32_t> members;
         for (uint32_t i = first; i < count && i < first + 8; i++) members.push_back(i);
         runs.bounds.push_back(cluster_bounds(boxes, members));
-        cost_runs += surface(runs.bounds.back());
     }
+    return runs;
+}
+
+ClusterSet build_clusters(const rt_aabb *boxes, uint32_t count)
+{
+    ClusterSet runs = run_clusters(boxes, count), spatial;
+    double cost_runs = 0, cost_spatial = 0;
+    for (const ClusterRecord &r : runs.bounds) cost_runs += surface(r);
     if (count <= 16) return runs;
     std::vector<uint32_t> all(count);
     for (uint32_t i = 0; i < count; i++) all[i] = i;
@@ -499,7 +508,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     auto shader_of = [](uint32_t id) { return (id >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK; };
     std::vector<uint8_t> kind(n_groups, 0xFF);
     std::vector<uint32_t> work;
-    bool any_ortho = false;
+    bool any_ortho = false, any_long = false;
     auto visit = [&](uint32_t id, const char *where) -> int {
         const uint32_t gi = id & RT_GROUP_ID_MASK, sh = shader_of(id);
         if (((id >> RT_GROUP_TR_SHIFT) & RT_GROUP_TR_MASK) == RT_TR_ORTHO) any_ortho = true;
@@ -553,10 +562,13 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
             dev_boxes.insert(dev_boxes.end(), aabb + s.aabb_offs, aabb + s.aabb_offs + s.aabb_count);
             while (dev_boxes.size() % 8) dev_boxes.push_back(never);
             // clusters of the list: [bounds, filled up to a multiple of four][membership masks, if any]
-            // (a list of more than kMaxClusteredBoxes boxes gets no clusters: every visit of it is left to the one-ray-per-wave kernel)
-            const ClusterSet set = s.aabb_count <= kMaxClusteredBoxes ? build_clusters(aabb + s.aabb_offs, s.aabb_count) : ClusterSet{};
-            const uint32_t clusters = uint32_t(set.bounds.size());
-            entry[2] = (s.flags & 0xFFu) | clusters << kClusterCountShift | (set.masks.empty() ? 0u : kClusterMasked);
+            // (a list of more than kMaxClusteredBoxes boxes gets one cluster per eight consecutive boxes; the kernel works out
+            // how many of them each part of 256 boxes has)
+            const bool long_list = s.aabb_count > kMaxClusteredBoxes;
+            any_long = any_long || long_list;
+            const ClusterSet set = long_list ? run_clusters(aabb + s.aabb_offs, s.aabb_count) : build_clusters(aabb + s.aabb_offs, s.aabb_count);
+            const uint32_t clusters = long_list ? 0u : uint32_t(set.bounds.size());
+            entry[2] = (s.flags & 0xFFu) | clusters << kClusterCountShift | (set.masks.empty() ? 0u : kClusterMasked) | (long_list ? kClusterLong : 0u);
             entry[3] = uint32_t(dev_clusters.size());
             dev_clusters.insert(dev_clusters.end(), set.bounds.begin(), set.bounds.end());
             while (dev_clusters.size() % 4) dev_clusters.push_back(no_cluster);
@@ -603,6 +615,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     RT_HIP(c, hipStreamSynchronize(c->stream));
     free_scene(c);
     c->group_count = G;
+    c->long_lists = any_long;
     c->cam = data->cam;
     RT_HIP(c, dev_alloc(c->grp, G));
     RT_HIP(c, dev_alloc(c->mat, n_mat));

@@ -90,9 +90,10 @@ union alignas(32) ClusterRecord {
     uint32_t u[8];
 };
 // Device copy of a box group's entry: {first box, boxes, flags | clusters << 8 | masked << 16, first cluster record}.
-constexpr uint32_t kClusterCountShift = 8, kClusterCountMask = 0xFF, kClusterMasked = 1u << 16;
-// The box kernel keeps a candidate's place in its list in one byte and a list's clusters in a 32-bit mask; longer
-// lists (up to kMaxListBoxes, two bytes per place) are visited by the one-ray-per-wave kernel only.
+constexpr uint32_t kClusterCountShift = 8, kClusterCountMask = 0xFF, kClusterMasked = 1u << 16, kClusterLong = 1u << 17;
+// A list's clusters sit in a 32-bit mask while its boxes are scanned, 256 boxes at a time; a longer list
+// (kClusterLong; up to kMaxListBoxes boxes, two bytes per place in the candidate columns) has one cluster per
+// eight consecutive boxes and is scanned part by part.
 constexpr uint32_t kMaxClusteredBoxes = 256, kMaxListBoxes = 65536;
 
 struct Scene {

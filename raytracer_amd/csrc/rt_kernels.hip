@@ -757,9 +757,9 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
 // caller hands every lane that ray's group and slot): the scan and the candidate sort are done by
 // wave_visit_one in the wave's lists c_pos/c_idx with the reference's limit of 64 candidates, and
 // only the lane `owner` merges and stores.
-template <int CAP, int THREADS, bool COOP, bool LEAN, bool FRESH = false>
+template <int CAP, int THREADS, bool COOP, bool LEAN, bool FRESH = false, typename PLACE = uint8_t>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
-                                           uint8_t (*s_idx)[THREADS], float *c_pos, uint16_t *c_idx, uint32_t owner,
+                                           PLACE (*s_idx)[THREADS], float *c_pos, uint16_t *c_idx, uint32_t owner,
                                            uint32_t tid, uint32_t &new_key, uint32_t &group_flags, uint32_t sample = 0)
 {
     AABB_STAMP(t_start);
@@ -795,17 +795,38 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     // in the order the reference's loop does (shader.cl:84-99).  The device copies of both lists are
     // filled up with entries no ray can enter and followed by readable spare entries: the loops have
     // no tail handling and always have the next 128 bytes in flight while the current ones are tested.
-    if (count > kMaxClusteredBoxes) {  // places in such a list do not fit the columns' bytes
+    // A list of more than 256 boxes (kClusterLong) is scanned 256 boxes -- 32 clusters of eight consecutive
+    // boxes -- at a time; any other list in one go.  Places in such a list take two bytes: a kernel whose
+    // columns hold one leaves the visit to the one-ray-per-wave kernel.
+    if (sizeof(PLACE) == 1 && count > kMaxClusteredBoxes) {
         if (FRESH) put_fresh_sample_in_its_slot();
         return false;
     }
     asm volatile("" ::"v"(inv_dir.x), "v"(inv_dir.y), "v"(inv_dir.z), "v"(lr.start.x));
     AABB_STAMP(t_loaded);
     bool spill = false;
+    const bool long_list = (grp.z & kClusterLong) != 0;
+#ifdef RT_COUNT_SCANNED
+    uint32_t scanned = 0;
+#endif
+    auto test_box = [&](const f32x8 b, uint32_t i) {
+        float t;
+        if (box_test(b, lr.start, inv_dir, lr.tmin, lr.tmax, t)) {
+            if (n < CAP) {
+                s_pos[n][tid] = t;
+                s_idx[n][tid] = (PLACE)i;
+                n++;
+            } else {
+                spill = true;
+            }
+        }
+    };
+    for (uint32_t seg = 0;;) {  // seg: first box of the part being scanned
     uint32_t entered = 0;
-    const uint32_t clusters = (grp.z >> kClusterCountShift) & kClusterCountMask;
+    uint32_t clusters = (grp.z >> kClusterCountShift) & kClusterCountMask;
+    if (long_list) clusters = count - seg > kMaxClusteredBoxes ? kMaxClusteredBoxes / 8 : (count - seg + 7) / 8;
     if (clusters) {
-        ConstPtr<f32x16> two = const_ptr<f32x16>(a.scene.cluster + grp.w);  // bounds of two clusters per load
+        ConstPtr<f32x16> two = const_ptr<f32x16>(a.scene.cluster + grp.w + seg / 8);  // bounds of two clusters per load
         auto test_two = [&](const f32x16 p, uint32_t c) {
             float t;
             if (__ballot(box_test(p.lo, lr.start, inv_dir, lr.tmin, lr.tmax, t))) entered |= 1u << c;
@@ -824,23 +845,11 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         }
     }
 #ifdef RT_COUNT_SCANNED
-    uint32_t scanned = clusters;
+    scanned += clusters;
 #endif
-    auto test_box = [&](const f32x8 b, uint32_t i) {
-        float t;
-        if (box_test(b, lr.start, inv_dir, lr.tmin, lr.tmax, t)) {
-            if (n < CAP) {
-                s_pos[n][tid] = t;
-                s_idx[n][tid] = (uint8_t)i;
-                n++;
-            } else {
-                spill = true;
-            }
-        }
-    };
     if (!(grp.z & kClusterMasked)) {
         // cluster c = boxes [8c, 8c + 8): two loads of 128 bytes per half cluster, ping-pong
-        ConstPtr<f32x16> pair = const_ptr<f32x16>(a.scene.aabb + grp.x);  // per box: min.xyz, group id, max.xyz, local id
+        ConstPtr<f32x16> pair = const_ptr<f32x16>(a.scene.aabb + grp.x + seg);  // per box: min.xyz, group id, max.xyz, local id
         if (entered) {
             uint32_t c = (uint32_t)__builtin_ctz(entered);
             entered &= entered - 1;
@@ -848,20 +857,20 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
             for (;;) {
                 scalar_loads_landed();  // a0, a1 are in; only then ask for the next four boxes
                 const f32x16 b0 = pair[4 * c + 2], b1 = pair[4 * c + 3];
-                test_box(a0.lo, 8 * c);
-                test_box(a0.hi, 8 * c + 1);
-                test_box(a1.lo, 8 * c + 2);
-                test_box(a1.hi, 8 * c + 3);
+                test_box(a0.lo, seg + 8 * c);
+                test_box(a0.hi, seg + 8 * c + 1);
+                test_box(a1.lo, seg + 8 * c + 2);
+                test_box(a1.hi, seg + 8 * c + 3);
                 const bool more = entered != 0;
                 const uint32_t next = more ? (uint32_t)__builtin_ctz(entered) : c;  // (a harmless reload at the end)
                 entered &= entered - 1;
                 scalar_loads_landed();
                 a0 = pair[4 * next];
                 a1 = pair[4 * next + 1];
-                test_box(b0.lo, 8 * c + 4);
-                test_box(b0.hi, 8 * c + 5);
-                test_box(b1.lo, 8 * c + 6);
-                test_box(b1.hi, 8 * c + 7);
+                test_box(b0.lo, seg + 8 * c + 4);
+                test_box(b0.hi, seg + 8 * c + 5);
+                test_box(b1.lo, seg + 8 * c + 6);
+                test_box(b1.hi, seg + 8 * c + 7);
 #ifdef RT_COUNT_SCANNED
                 scanned += 8;
 #endif
@@ -916,6 +925,9 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         scan_word(m2, 128);
         scan_word(m3, 192);
     }
+    seg += kMaxClusteredBoxes;
+    if (!long_list || seg >= count) break;
+    }
 #ifdef RT_COUNT_SCANNED
     count_lanes(a.frame, kBoxScanned, true, scanned);
 #endif
@@ -947,7 +959,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         if (i < n) {
             const float pj = s_pos[j][tid], pi = s_pos[i][tid];
             if (pj > pi) {
-                const uint8_t ij = s_idx[j][tid], ii = s_idx[i][tid];
+                const PLACE ij = s_idx[j][tid], ii = s_idx[i][tid];
                 s_pos[j][tid] = pi;  s_pos[i][tid] = pj;
                 s_idx[j][tid] = ii;  s_idx[i][tid] = ij;
             }
@@ -1114,13 +1126,12 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 // FREE (free schedule): the kernel also re-initialises finished slots (key 0) as new samples and
 // sends them through the scene root in the same launch, runs end-group shaders on the spot
 // (run_end_group) and carries the parked entries over, so no shading launch is needed.
-template <bool FREE>
-__attribute__((amdgpu_waves_per_eu(RT_AABB_WAVES, 8)))
-__global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, uint32_t *spill_list)
+// PLACE: one byte per candidate's place in its list, or two for scenes with lists of more than 256 boxes
+// (24 instead of 20 KB of LDS per workgroup, i.e. six instead of seven workgroups per CU).
+template <bool FREE, typename PLACE>
+__device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spill_list, float (*s_pos)[kAabbThreads],
+                                             PLACE (*s_idx)[kAabbThreads])
 {
-    __shared__ float s_pos[kAabbCap][kAabbThreads];
-    __shared__ uint8_t s_idx[kAabbCap][kAabbThreads];
-
     const uint32_t tid = threadIdx.x;
     const uint32_t index = blockIdx.x * blockDim.x + tid;
     DevGlobal *glob = a.frame.glob;
@@ -1170,7 +1181,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
         // The samples that start here all enter the camera's root: a visit of its own, with the ray worked out in
         // registers and no pending entries.  A ray that comes out of an instance list at a model's root goes on below.
         uint32_t group_flags = 0;
-        done = visit_aabb<kAabbCap, kAabbThreads, false, true, true>(uniform_value(key), ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid,
+        done = visit_aabb<kAabbCap, kAabbThreads, false, true, true, PLACE>(uniform_value(key), ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid,
                                                                      new_key, group_flags, sample);
         visit = done && (group_flags & RT_F_LOCAL0) && ((new_key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_AABB;
         asm volatile("" ::: "memory");  // the next visit reads what this one has stored to the slot
@@ -1183,7 +1194,8 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
             if (key != __builtin_amdgcn_readfirstlane(key)) continue;
             todo = false;
             const uint32_t g = uniform_value(key);  // every lane still here holds the same key
-            done = visit_aabb<kAabbCap, kAabbThreads, false, FREE>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key, group_flags);
+            done = visit_aabb<kAabbCap, kAabbThreads, false, FREE, false, PLACE>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key,
+                                                                                  group_flags);
         }
         // Free schedule: a ray that has just been through a list of instances (the scene root) and whose
         // nearest node is a model's root goes through that root now.  A wave's rays enter few distinct
@@ -1219,9 +1231,27 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
 #endif
 }
 
+template <bool FREE>
+__attribute__((amdgpu_waves_per_eu(RT_AABB_WAVES, 8)))
+__global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, uint32_t *spill_list)
+{
+    __shared__ float s_pos[kAabbCap][kAabbThreads];
+    __shared__ uint8_t s_idx[kAabbCap][kAabbThreads];
+    process_aabb<FREE, uint8_t>(a, spill_list, s_pos, s_idx);
+}
+
+// The same with two-byte places, for scenes with box lists of more than 256 boxes.
+template <bool FREE>
+__global__ __launch_bounds__(kAabbThreads) void k_process_aabb_wide(ProcessArgs a, uint32_t *spill_list)
+{
+    __shared__ float s_pos[kAabbCap][kAabbThreads];
+    __shared__ uint16_t s_idx[kAabbCap][kAabbThreads];
+    process_aabb<FREE, uint16_t>(a, spill_list, s_pos, s_idx);
+}
+
 // The box visits the main kernel left undone, one wave per ray: a lone lane scanning a 256-box list and
 // sorting 30 candidates in its own columns takes about 50 us, a wave sharing the work a few.
-constexpr int kBigThreads = 256, kBigBlocks = 256;
+constexpr int kBigThreads = 256, kBigBlocks = 1024;
 
 template <bool FREE>
 __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a, const uint32_t *spill_list)
@@ -1238,7 +1268,7 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
         const uint32_t g = uniform_value(ray->queue[0].group_id);
         uint32_t new_key = g;
         uint32_t group_flags;
-        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true, FREE>(g, ray, a, nullptr, nullptr, s_wave_pos[wave], s_wave_idx[wave], 0, tid,
+        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true, FREE, false, uint8_t>(g, ray, a, nullptr, nullptr, s_wave_pos[wave], s_wave_idx[wave], 0, tid,
                                                         new_key, group_flags);
         if (lane_id() == 0) {
             if (FREE) new_key = run_end_group(new_key, ray, a);
@@ -1565,11 +1595,14 @@ void launch_load_rays(const LaunchCtx &c, const rt_ray *rays, uint32_t n_rays)
 void launch_process_boxes(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
+    const dim3 grid = grid_for(c.pool, kAabbThreads);
     if (c.free_schedule) {
-        k_process_aabb<true><<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+        if (c.long_lists) k_process_aabb_wide<true><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+        else k_process_aabb<true><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
         k_process_aabb_big<true><<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
     } else {
-        k_process_aabb<false><<<grid_for(c.pool, kAabbThreads), kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+        if (c.long_lists) k_process_aabb_wide<false><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+        else k_process_aabb<false><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
         k_process_aabb_big<false><<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
     }
 }

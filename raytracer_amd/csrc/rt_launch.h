@@ -15,6 +15,7 @@ struct LaunchCtx {
     CompactWorkspace compact;
     uint32_t pool, area_size, group_count;
     bool free_schedule;  // RT_FLAG_FREE_SCHEDULE: shading and spawn inside the visiting kernels, no shading launch
+    bool long_lists;     // the scene has a box list of more than 256 boxes: the box kernel with two-byte places
 };
 
 void launch_init_frame(const LaunchCtx &c);
