@@ -183,7 +183,7 @@ def test_free_schedule_keeps_the_step_invariants(bunny_scene_128):
     """Sorted by group, whole waves per group, every slot exactly once, no shader key left in the index."""
     rt = api.RayTracer(bunny_scene_128, warp_width=64, free_schedule=True)
     rt.init_frame()
-    pool, prev = rt.pool, rt.pool
+    pool, prev, checked = rt.pool, rt.pool, 0
     for chunk in range(6):
         rt.make_step(8)
         g = rt.global_data()[0]
@@ -198,8 +198,19 @@ def test_free_schedule_keeps_the_step_invariants(bunny_scene_128):
         # a travelling ray's head is its key; a finished slot (key 0) keeps whatever its last sample left
         live = index["key"][:n] != 0
         assert np.array_equal(rays["queue"]["group_id"][index["slot"][:n][live], 0], index["key"][:n][live])
+        # its queue (exported from the stack the free schedule keeps) is in order of entry position, nearest first,
+        # and holds groups of the scene only
+        q = rays["queue"][index["slot"][:n][live]]
+        qlen = rays["queue_len"][index["slot"][:n][live]]
+        checked += int(live.sum())
+        assert not live.any() or (qlen.min() >= 1 and qlen.max() <= 8)
+        for k in range(1, 8):
+            has = qlen > k
+            assert np.all(q["pos"][has, k] >= q["pos"][has, k - 1])
+            assert np.all((q["group_id"][has, k] & L.GROUP_ID_MASK) < bunny_scene_128.group_count)
         assert int(g["pixel_offset"]) >= prev
         prev = int(g["pixel_offset"])
+    assert checked > 1000
     c = rt.counters()
     assert int(c["primary_spawned"]) == prev
     rt.close()
