@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb_wide(ProcessArgs 
 
 // The box visits the main kernel left undone, one wave per ray: a lone lane scanning a 256-box list and
 // sorting 30 candidates in its own columns takes about 50 us, a wave sharing the work a few.
-constexpr int kBigThreads = 256, kBigBlocks = 1024;
+constexpr int kBigThreads = 256, kBigBlocks = 256;
 
 template <bool FREE>
 __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a, const uint32_t *spill_list)

@@ -23,6 +23,11 @@ PASSES = {
               "TCP_UTCL1_STALL_INFLIGHT_MAX_sum"],
     "tcp_d": ["TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", "TCP_WRITE_TAGCONFLICT_STALL_CYCLES_sum", "TCP_LFIFO_STALL_CYCLES_sum",
               "TCP_RFIFO_STALL_CYCLES_sum"],
+    # the scalar path (--passes sqc_a,sqc_b)
+    "sqc_a": ["SQC_DCACHE_REQ", "SQC_DCACHE_HITS", "SQC_DCACHE_MISSES", "SQC_DCACHE_MISSES_DUPLICATE", "SQC_DCACHE_BUSY_CYCLES",
+              "SQC_TC_DATA_READ_REQ", "SQC_TC_STALL", "SQ_INST_LEVEL_SMEM"],
+    "sqc_b": ["SQC_ICACHE_REQ", "SQC_ICACHE_HITS", "SQC_ICACHE_MISSES", "SQC_ICACHE_BUSY_CYCLES", "SQ_IFETCH", "SQ_IFETCH_LEVEL",
+              "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"],
 }
 DEFAULT_PASSES = "sq_a,sq_b,fetch,write,l2,grbm"
 
