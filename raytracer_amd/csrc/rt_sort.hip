@@ -23,6 +23,9 @@ constexpr uint32_t kRadix = 1u << kRadixBits;
 // Plain-order sorts (free schedule) are free to use smaller tiles: four times as many workgroups, a
 // quarter of the LDS each, so that several are resident per CU and the passes stop being latency-bound.
 constexpr uint32_t kSmallTile = 2048, kSmallThreads = 256;
+#ifndef RT_RANK_THREADS
+#define RT_RANK_THREADS 1024
+#endif
 static_assert(kTile == kSmallTile * kSortCountsPerTile, "pools are whole reference tiles, hence whole small tiles");
 
 // Key bits the reference's pass loop covers: 5 bits per pass while (group_count-1) >> 5p is non-zero,
@@ -295,29 +298,32 @@ struct Placement {
     uint32_t count, group_blocks, tile_blocks, groups;
 };
 
-// Rank of every one of the first n pairs inside its group, one small tile per workgroup: the tile's pairs are
+// Rank of every one of the first n pairs inside its group, one tile of 8,192 pairs per workgroup of 1,024 threads
+// (the dense per-group counters in LDS are cleared and walked by four times as many threads as with 256, and
+// every workgroup is still resident at once): the tile's pairs are
 // counted per group in LDS, handing each its rank among the tile's pairs of that group; one atomic per
 // non-empty group then reserves the tile's range in the group and returns where it starts.  s_group: [groups].
-__global__ __launch_bounds__(kSmallThreads) void k_fused_rank(const rt_index_pair *src, DevGlobal *glob, uint32_t *ghist,
+constexpr uint32_t kRankThreads = RT_RANK_THREADS, kRankTile = 8 * kRankThreads;  // pairs per workgroup of the rank kernel
+__global__ __launch_bounds__(kRankThreads) void k_fused_rank(const rt_index_pair *src, DevGlobal *glob, uint32_t *ghist,
                                                               uint32_t *rank, uint32_t groups)
 {
     extern __shared__ uint32_t s_group[];
-    constexpr uint32_t kPerThread = kSmallTile / kSmallThreads;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, base = blockIdx.x * kSmallTile, n = glob->g.ray_count;
+    constexpr uint32_t kPerThread = kRankTile / kRankThreads;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, base = blockIdx.x * kRankTile, n = glob->g.ray_count;
     if (blockIdx.x == 0 && tid == 0) glob->sort_count = n;  // the later kernels run after the live count has been replaced
     if (base >= n) return;
     uint32_t keys[kPerThread], local[kPerThread];
 #pragma unroll
     for (uint32_t i = 0; i < kPerThread; i++) {
-        const uint32_t p = base + i * kSmallThreads + tid;
+        const uint32_t p = base + i * kRankThreads + tid;
         keys[i] = p < n ? src[p].key : 0xFFFFFFFFu;
     }
-    for (uint32_t i = tid; i < groups; i += kSmallThreads) s_group[i] = 0;
+    for (uint32_t i = tid; i < groups; i += kRankThreads) s_group[i] = 0;
     __syncthreads();
     const unsigned long long lanes_below = (1ull << lane) - 1;
 #pragma unroll
     for (uint32_t i = 0; i < kPerThread; i++) {
-        bool todo = base + i * kSmallThreads + tid < n;
+        bool todo = base + i * kRankThreads + tid < n;
         uint32_t id = keys[i] & kIdMask;
         id = id < groups ? id : groups - 1;
         keys[i] = id;
@@ -344,26 +350,26 @@ __global__ __launch_bounds__(kSmallThreads) void k_fused_rank(const rt_index_pai
     __syncthreads();
     // (eight reservations in flight per thread: one after the other they would take a memory round trip each)
     constexpr uint32_t kBatch = 8;
-    for (uint32_t first = tid; first < groups; first += kBatch * kSmallThreads) {
+    for (uint32_t first = tid; first < groups; first += kBatch * kRankThreads) {
         uint32_t c[kBatch], start[kBatch];
 #pragma unroll
         for (uint32_t k = 0; k < kBatch; k++) {
-            const uint32_t g = first + k * kSmallThreads;
+            const uint32_t g = first + k * kRankThreads;
             c[k] = g < groups ? s_group[g] : 0u;
         }
 #pragma unroll
         for (uint32_t k = 0; k < kBatch; k++) {
             start[k] = 0;
-            if (c[k]) start[k] = atomicAdd(&ghist[first + k * kSmallThreads], c[k]);
+            if (c[k]) start[k] = atomicAdd(&ghist[first + k * kRankThreads], c[k]);
         }
 #pragma unroll
         for (uint32_t k = 0; k < kBatch; k++)
-            if (c[k]) s_group[first + k * kSmallThreads] = start[k];
+            if (c[k]) s_group[first + k * kRankThreads] = start[k];
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t i = 0; i < kPerThread; i++) {
-        const uint32_t p = base + i * kSmallThreads + tid;
+        const uint32_t p = base + i * kRankThreads + tid;
         if (p < n) rank[p] = local[i] + s_group[keys[i]];
     }
 }
@@ -495,7 +501,7 @@ void launch_fused(hipStream_t stream, const SortWorkspace &ws, const FusedWorksp
     uint32_t *rank = reinterpret_cast<uint32_t *>(ws.tmp);  // one word per pair in the sort's ping-pong buffer
     const Placement pl{glob, grp_data, cw.move, cw.block_sums, fw.block_main, count, group_blocks, tiles, group_count};
     const uint32_t place_grid = tiles > group_blocks ? tiles : group_blocks;
-    k_fused_rank<<<tiles, kSmallThreads, fused_hist_lds_bytes(group_count), stream>>>(in, glob, fw.ghist, rank, group_count);
+    k_fused_rank<<<count / kRankTile, kRankThreads, fused_hist_lds_bytes(group_count), stream>>>(in, glob, fw.ghist, rank, group_count);
     k_fused_groups<<<group_blocks, kGroupThreads, 0, stream>>>(glob, grp_data, fw.ghist, cw, fw.block_main, group_blocks);
     k_fused_place<<<place_grid, kGroupThreads, 0, stream>>>(in, rank, out, pl);
 }
