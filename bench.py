@@ -241,7 +241,6 @@ def main():
                 torch.cuda.synchronize()
 
     settled, steady = settle(rt, args.settle)
-    rt.make_step(args.warmup)
     barrier()
     t_g = time.perf_counter()
     resolve_and_gather()
@@ -251,6 +250,9 @@ def main():
     rt.draw_frame(host_band)                       # the same resolve plus the copy of the band to host memory
     readback_ms = (time.perf_counter() - t_h) * 1e3
     keys = ("primary_spawned", "shadow_spawned", "box_tests", "tri_tests")
+    # the warm-up steps come last before the timed region (the frame read-back above leaves the GPU idle for milliseconds)
+    rt.make_step(args.warmup)
+    barrier()
     c0 = rt.counters()
     rt.set_profiling(1 if args.stage_timers == "timed" else 0)
     t0 = time.perf_counter()
