@@ -32,7 +32,12 @@ for name, c in sorted(src.items()):
         "lds_wave_instructions": c.get("SQ_INSTS_LDS"),
         "vmem_read_wave_instructions": c.get("SQ_INSTS_VMEM_RD"),
         "vmem_write_wave_instructions": c.get("SQ_INSTS_VMEM_WR"),
-        # a wave64 VALU instruction holds a SIMD for 2 cycles
+        # share of the SIMDs' cycles in which a vector instruction executes (rocprof's VALUBusy: SQ_ACTIVE_INST_VALU is
+        # in units of four cycles and covers what an instruction really takes -- packed and transcendental ones more
+        # than the two cycles of a plain wave64 operation), and the share of lanes active in those instructions
+        "valu_busy": 4 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / simd_cycles if simd_cycles else None,
+        "valu_lanes_active": c.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, 64 * c.get("SQ_ACTIVE_INST_VALU", 0.0)),
+        # lower bound of the same: every instruction counted as a plain wave64 operation of two cycles
         "valu_utilisation": 2 * c.get("SQ_INSTS_VALU", 0.0) / simd_cycles if simd_cycles else None,
         "wave_quad_cycles": c.get("SQ_WAVE_CYCLES"),
         "share_waiting": c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0.0)),
@@ -50,4 +55,4 @@ stamp = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "
 json.dump(stamp, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for k, r in report.items():
     print(f"{k:18s} rd {r['hbm_read_bytes']/1e6:7.1f} MB wr {r['hbm_write_bytes']/1e6:7.1f} MB  L2 hit {r['l2_hit_rate']:.2f}  "
-          f"VALU util {r['valu_utilisation'] or 0:.2f}  wait {r['share_waiting']:.2f} stall {r['share_issue_stalled']:.2f} issue {r['share_issuing']:.2f}")
+          f"VALU busy {r['valu_busy'] or 0:.2f} (lanes {r['valu_lanes_active']:.2f})  wait {r['share_waiting']:.2f} stall {r['share_issue_stalled']:.2f} issue {r['share_issuing']:.2f}")
