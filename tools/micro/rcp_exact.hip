@@ -51,6 +51,7 @@ struct Tally {
     uint32_t first_bad_packed;
     unsigned long long bad_raw[2], bad_guarded[2], guarded_out[2];
     uint32_t first_bad[2], min_exp_bad[2], max_exp_bad[2];
+    unsigned long long bad_by_exp[2][256];  // mismatches without guard, by biased exponent of the input
 };
 
 __global__ void k(Tally *t, uint32_t base)
@@ -72,6 +73,7 @@ __global__ void k(Tally *t, uint32_t base)
     for (int v = 0; v < 2; v++) {
         if (!same(qs[v], ref)) {
             atomicAdd(&t->bad_raw[v], 1ull);
+            atomicAdd(&t->bad_by_exp[v][(bits >> 23) & 0xFF], 1ull);
             if (ok) {
                 atomicAdd(&t->bad_guarded[v], 1ull);
                 atomicMin(&t->first_bad[v], bits);
@@ -102,6 +104,12 @@ int main()
     for (int v = 0; v < 2; v++)
         printf("variant %d: mismatches without guard %llu, with guard %llu (first 0x%08x, exponents %u..%u), values sent to the full division %llu\n",
                v, h.bad_raw[v], h.bad_guarded[v], h.first_bad[v], h.min_exp_bad[v], h.max_exp_bad[v], h.guarded_out[v]);
+    for (int v = 0; v < 2; v++) {
+        printf("variant %d, biased exponents of the inputs with a mismatch (no guard):", v);
+        for (int e = 0; e < 256; e++)
+            if (h.bad_by_exp[v][e]) printf(" %d:%llu", e, h.bad_by_exp[v][e]);
+        printf("\n");
+    }
     printf("packed division sequence: mismatches %llu (first 0x%08x)\n", h.bad_packed, h.first_bad_packed);
     return 0;
 }
