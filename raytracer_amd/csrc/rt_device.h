@@ -276,6 +276,21 @@ __device__ __forceinline__ uint32_t uniform_value(uint32_t v)
     return s;
 }
 
+// A field of the frame state that no kernel of the process stage writes (limits, modes, the counts the grouping left),
+// read through the scalar path: one request for the wave, and not among the vector requests -- a vector load between
+// two stores makes the wave wait for the first store as well.
+template <typename T>
+__device__ __forceinline__ T step_constant(const T *field)
+{
+    return *const_ptr<T>(field);
+}
+
+// Waits for every vector load issued so far (and every store: they share the counter).
+__device__ __forceinline__ void vector_loads_landed()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
+}
+
 // Waits for every scalar load (and LDS access) issued so far.  Scalar loads return out of order, so a
 // wave can only wait for all of them; in a software-pipelined scan this goes BEFORE the request for the
 // next batch, otherwise the first use of the current batch waits for the batch just requested as well.

@@ -103,7 +103,7 @@ __device__ __forceinline__ HotRay camera_ray(const rt_camera &cam, const DevGlob
     deinterleave(sample / total, sx, sy);
     const uint32_t pixel = sample % total;
     const float x = (float)(pixel % cam.width) + subpixel(sx);
-    const float y = (float)(pixel / cam.width + glob->row_offset) + subpixel(sy);
+    const float y = (float)(pixel / cam.width + step_constant(&glob->row_offset)) + subpixel(sy);
     const V3 tl = v3(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
     const V3 dx = v3(cam.dx[0], cam.dx[1], cam.dx[2]), dy = v3(cam.dy[0], cam.dy[1], cam.dy[2]);
     HotRay h;
@@ -144,12 +144,12 @@ template <bool LEAN>
 __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlobal *glob, RaySlot *ray,
                                              rt_hit_record *hits, uint32_t group_count, uint32_t sample, bool &started)
 {
-    const uint32_t limit = glob->sample_limit;
+    const uint32_t limit = step_constant(&glob->sample_limit);
     started = !(limit && sample >= limit);
     if (!started) return group_count - 1;
     if (!LEAN) ray->weight = make_float4(1, 1, 1, 1);
     if (!LEAN) ray->root = RayHit{0.0f, cam.root_group, cam.root_local, 0u};
-    if (sample < glob->hit_capacity) hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (sample < step_constant(&glob->hit_capacity)) hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     return reset_ray<LEAN>(ray, camera_ray(cam, glob, sample), cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
 }
 
@@ -418,28 +418,41 @@ __device__ __forceinline__ uint32_t run_end_group(uint32_t key, RaySlot *ray, co
     const uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
     if (shader == RT_SH_SPAWN || shader >= RT_SH_AABB) return key;
     asm volatile("" ::: "memory");  // the shader reads what the visit has just stored to the slot
-    if (a.frame.glob->mode & kModeTraceOnly) return a.group_count - 1;
+    if (step_constant(&a.frame.glob->mode) & kModeTraceOnly) return a.group_count - 1;
     if (shader != RT_SH_MATERIAL) return sky_or_light_shader<true>(a, ray, shader == RT_SH_LIGHT);
     const float4 color = *reinterpret_cast<const float4 *>(a.scene.grp + (key & kIdMask));
     count_lanes(a.frame, kShadowSpawned, true);
-    return mat_shader<true>(ray, color, a.frame.glob->shading);
+    return mat_shader<true>(ray, color, step_constant(&a.frame.glob->shading));
 }
 
 // Asks for the 64-byte lines of a wave-uniform list ahead of the scan that reads it through the scalar path one
 // batch after the other: the wave's active lanes touch up to four lines each, all requests in flight together, so
-// that by the time the scan gets to a line it is in the L2 cache.  The sum of the touched words is returned and has
-// to be handed to touch_done() after the scan (that is what keeps the loads, and where they are waited for).
-__device__ __forceinline__ uint32_t touch_list(const void *list, uint32_t bytes)
+// that by the time the scan gets to a line it is in the L2 cache.  touch_list() issues the loads; touch_sum() adds the
+// touched words up (one register instead of four across the scan), and the sum has to be handed to touch_done() after
+// the scan: that is what keeps the loads.
+struct Touched {
+    uint32_t v[4];
+};
+__device__ __forceinline__ Touched touch_list(const void *list, uint32_t bytes)
 {
     const unsigned long long active = __ballot(true);
     const uint32_t workers = (uint32_t)__popcll(active), rank = (uint32_t)__popcll(active & ((1ull << lane_id()) - 1));
     const char *base = static_cast<const char *>(list);
-    uint32_t sum = 0;
+    // No branch around a load (each would get a wait of its own): a lane with nothing left to ask for asks for the
+    // list's last line again.
+    const uint32_t last = bytes ? (bytes - 1) & ~63u : 0u;  // (an empty list is followed by readable entries)
+    Touched t;
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
         const uint32_t at = (rank + k * workers) * 64;
-        if (at < bytes) sum += *reinterpret_cast<const uint32_t *>(base + at);
+        t.v[k] = *reinterpret_cast<const uint32_t *>(base + (at < last ? at : last));
     }
+    return t;
+}
+__device__ __forceinline__ uint32_t touch_sum(const Touched &t)
+{
+    uint32_t sum = (t.v[0] + t.v[1]) + (t.v[2] + t.v[3]);
+    asm volatile("" : "+v"(sum));
     return sum;
 }
 __device__ __forceinline__ void touch_done(uint32_t sum) { asm volatile("" ::"v"(sum)); }
@@ -458,7 +471,9 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
     const uint32_t queue_len = h.queue_len;
     const RayHit head = ray->queue[0];
     const LocalRay lr = make_local(g, h, head.local0, a.scene.mat);
-    const uint32_t touched = touch_list(a.scene.tri_rec + grp.y, (grp.z + 1) / 2 * (2 * (uint32_t)sizeof(TriRecord)));
+    // (asked for before the instance matrix the leaf kernel is 1 % faster alone, but the four registers the requests
+    // hold across the transformation cost 12 bytes of scratch and the step comes out slower)
+    const uint32_t touched = touch_sum(touch_list(a.scene.tri_rec + grp.y, (grp.z + 1) / 2 * (2 * (uint32_t)sizeof(TriRecord))));
 
     count_lanes(a.frame, kTriTests, true, grp.z);
     // Triangle scan.  Leaf payload is wave-uniform and comes through the scalar cache, two triangles at a time:
@@ -557,7 +572,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
             ray->norm = make_float4(nw.x, nw.y, nw.z, 0.0f);
             if (!LEAN) ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
             // the record is the camera ray's hit: a sample that has bounced keeps it
-            if (h.type == RT_RAY_PRIMARY && sid < a.frame.glob->hit_capacity) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
+            if (h.type == RT_RAY_PRIMARY && sid < step_constant(&a.frame.glob->hit_capacity)) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
         }
         store_commit(ray, end_group, h.type, len, t_min, new_max);
     };
@@ -593,6 +608,9 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
         }
         if (len && !moved) next = ray->queue[len];
         if (len && next.pos >= (hit && shadow ? best : new_max)) len = 0;
+        // All that the stores below need from memory has been requested; waited for here, once, they go out back to
+        // back (otherwise the compiler waits in front of a store's operands for everything under way, stores included).
+        vector_loads_landed();
         if (len) {
             if (hit) commit_hit(len, head.pos);
             else store_progress(ray, h.type, len, head.pos);
@@ -760,7 +778,8 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
 template <int CAP, int THREADS, bool COOP, bool LEAN, bool FRESH = false, typename PLACE = uint8_t>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
                                            PLACE (*s_idx)[THREADS], float *c_pos, uint16_t *c_idx, uint32_t owner,
-                                           uint32_t tid, uint32_t &new_key, uint32_t &group_flags, uint32_t sample = 0)
+                                           uint32_t tid, uint32_t &new_key, uint32_t &group_flags, uint32_t sample = 0,
+                                           uint32_t head_lds = 0xFFFFFFFFu)
 {
     AABB_STAMP(t_start);
     MERGE_STAMP(t_m_start);
@@ -775,6 +794,15 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     const RayHit head = FRESH ? RayHit{0.001f, a.cam.root_group, a.cam.root_local, 0u} : ray->queue[0];
     const uint32_t old_len = FRESH ? 1u : h.queue_len;
     const float reach = h.t_max;
+    // The head's local ids go into every entry this visit adds.  Held in registers across the scan they get spilled,
+    // and a reload from scratch in front of each of those stores waits for the store before it (one counter for
+    // both).  So they wait in LDS (head_lds: the byte address of this lane's eight bytes there) and are read back
+    // entry by entry -- in assembly, which keeps the compiler from holding on to what was read.
+    const bool head_in_lds = !COOP && !FRESH && head_lds != 0xFFFFFFFFu;
+    if (head_in_lds) {
+        const unsigned long long both = (unsigned long long)head.local1 << 32 | head.local0;
+        asm volatile("ds_write_b64 %0, %1" ::"v"(head_lds), "v"(both) : "memory");
+    }
     auto put_fresh_sample_in_its_slot = [&]() {  // for the kernel that redoes a visit this one gives up
         store_hot(ray, h);
         ray->queue[0] = head;
@@ -832,16 +860,20 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
             if (__ballot(box_test(p.lo, lr.start, inv_dir, lr.tmin, lr.tmax, t))) entered |= 1u << c;
             if (__ballot(box_test(p.hi, lr.start, inv_dir, lr.tmin, lr.tmax, t))) entered |= 2u << c;
         };
-        f32x16 c0 = two[0];
-        for (uint32_t c = 0;; c += 4) {
+        // four clusters per round trip (the bounds are filled up to a multiple of four with clusters no ray enters)
+        f32x16 c0 = two[0], c1 = two[1];
+        for (uint32_t c = 0;; c += 8) {
             scalar_loads_landed();
-            const f32x16 c1 = two[c / 2 + 1];
+            const f32x16 d0 = two[c / 2 + 2], d1 = two[c / 2 + 3];
             test_two(c0, c);
-            if (c + 2 >= clusters) break;
-            scalar_loads_landed();
-            c0 = two[c / 2 + 2];
             test_two(c1, c + 2);
             if (c + 4 >= clusters) break;
+            scalar_loads_landed();
+            c0 = two[c / 2 + 4];
+            c1 = two[c / 2 + 5];
+            test_two(d0, c + 4);
+            test_two(d1, c + 6);
+            if (c + 8 >= clusters) break;
         }
     }
 #ifdef RT_COUNT_SCANNED
@@ -1070,6 +1102,11 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     auto place_pending = [&](int i) {
         if ((uint32_t)i < live_len) place(i - 1 + candidates_before(q[i].pos), q[i], old_len - i);
     };
+    // Everything the placement needs from memory (pending entries, child ids, the root entry) has been requested;
+    // one wait here, and the stores below go out back to back.  Without it the compiler, which cannot tell across the
+    // branches which loads are still under way, waits for all vector memory operations before each store's operands,
+    // i.e. also for the store before.
+    vector_loads_landed();
     if (some_old) {
 #pragma unroll
         for (int i = 1; i < 4; i++) place_pending(i);
@@ -1079,9 +1116,17 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         }
     }
     auto place_candidate = [&](int j) {
-        if ((uint32_t)j < n)
+        if ((uint32_t)j < n) {
+            uint32_t inherited0 = head.local0, inherited1 = head.local1;
+            if (head_in_lds) {
+                unsigned long long both;
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(both) : "v"(head_lds) : "memory");
+                inherited0 = (uint32_t)both;
+                inherited1 = (uint32_t)(both >> 32);
+            }
             place(j + (some_old ? pending_not_after(cand_pos[j]) : 0u),
-                  RayHit{cand_pos[j], cand_group[j], take0 ? cand_local[j] : head.local0, take1 ? cand_local[j] : head.local1}, kNowhere);
+                  RayHit{cand_pos[j], cand_group[j], take0 ? cand_local[j] : inherited0, take1 ? cand_local[j] : inherited1}, kNowhere);
+        }
     };
 #pragma unroll
     for (int j = 0; j < 4; j++) place_candidate(j);
@@ -1130,7 +1175,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 // (24 instead of 20 KB of LDS per workgroup, i.e. six instead of seven workgroups per CU).
 template <bool FREE, typename PLACE>
 __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spill_list, float (*s_pos)[kAabbThreads],
-                                             PLACE (*s_idx)[kAabbThreads])
+                                             PLACE (*s_idx)[kAabbThreads], uint32_t head_lds)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t index = blockIdx.x * blockDim.x + tid;
@@ -1147,7 +1192,7 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
     // the grid covers the pool exactly: the entry is requested before the live count has arrived
     const rt_index_pair entry = a.frame.index[index];
     uint32_t key = entry.key;
-    if (index >= glob->g.ray_count) {
+    if (index >= step_constant(&glob->g.ray_count)) {
         if (FREE) a.frame.next[index] = entry;  // parked entry: not processed, carried over
         return;
     }
@@ -1158,12 +1203,12 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
     uint32_t sample = 0;
     if (FREE) {
         if (key == RT_SPAWN_GROUP) {  // a finished slot: the next sample starts here and visits the root below
-            sample = blocked_sample(a.cam, glob->g.pixel_offset, glob->g.pixel_count, index);
-            const uint32_t limit = glob->sample_limit;
+            sample = blocked_sample(a.cam, step_constant(&glob->g.pixel_offset), step_constant(&glob->g.pixel_count), index);
+            const uint32_t limit = step_constant(&glob->sample_limit);
             fresh = !(limit && sample >= limit);
             count_lanes(a.frame, kPrimarySpawned, fresh);
             key = fresh ? a.cam.root_group : a.group_count - 1;
-            if (fresh && sample < glob->hit_capacity) a.frame.hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (fresh && sample < step_constant(&glob->hit_capacity)) a.frame.hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
         }
         if (shader != RT_SH_AABB) {
@@ -1195,7 +1240,7 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
             todo = false;
             const uint32_t g = uniform_value(key);  // every lane still here holds the same key
             done = visit_aabb<kAabbCap, kAabbThreads, false, FREE, false, PLACE>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key,
-                                                                                  group_flags);
+                                                                                  group_flags, 0, head_lds);
         }
         // Free schedule: a ray that has just been through a list of instances (the scene root) and whose
         // nearest node is a model's root goes through that root now.  A wave's rays enter few distinct
@@ -1208,6 +1253,11 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
     // Rare (3 visits in 10,000 on the benchmark scene): lanes whose columns overflowed and whose rays are
     // therefore untouched.  Their positions go to a list (one atomic per wave); k_process_aabb_big
     // performs those visits with one wave per ray.
+    // (the position is worked out again: held across the visits it is spilled, and its reload from scratch waits for
+    // every store of the visit, one counter for loads and stores)
+    uint32_t tid_again = tid;
+    asm volatile("" : "+v"(tid_again));
+    const uint32_t index_again = blockIdx.x * blockDim.x + tid_again;
     const unsigned long long spilled = __ballot(!done);
     if (spilled) {
         uint32_t base = 0;
@@ -1215,12 +1265,12 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
         if (lane_id() == leader) base = atomicAdd(&glob->spill_count, (uint32_t)__popcll(spilled));
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
         if (!done) {
-            spill_list[base + __popcll(spilled & ((1ull << lane_id()) - 1))] = index;
+            spill_list[base + __popcll(spilled & ((1ull << lane_id()) - 1))] = index_again;
             return;
         }
     }
     if (FREE) new_key = run_end_group(new_key, ray, a);
-    a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
+    a.frame.next[index_again] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 #if defined(RT_STAMPS) && RT_STAMPS == 3
     {
         unsigned long long trace_t1;
@@ -1237,7 +1287,8 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
 {
     __shared__ float s_pos[kAabbCap][kAabbThreads];
     __shared__ uint8_t s_idx[kAabbCap][kAabbThreads];
-    process_aabb<FREE, uint8_t>(a, spill_list, s_pos, s_idx);
+    __shared__ unsigned long long s_head[kAabbThreads];  // per lane: the head's two local ids (see visit_aabb)
+    process_aabb<FREE, uint8_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x]);
 }
 
 // The same with two-byte places, for scenes with box lists of more than 256 boxes.
@@ -1246,7 +1297,8 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb_wide(ProcessArgs 
 {
     __shared__ float s_pos[kAabbCap][kAabbThreads];
     __shared__ uint16_t s_idx[kAabbCap][kAabbThreads];
-    process_aabb<FREE, uint16_t>(a, spill_list, s_pos, s_idx);
+    __shared__ unsigned long long s_head[kAabbThreads];  // per lane: the head's two local ids (see visit_aabb)
+    process_aabb<FREE, uint16_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x]);
 }
 
 // The box visits the main kernel left undone, one wave per ray: a lone lane scanning a 256-box list and
@@ -1290,7 +1342,7 @@ __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     const rt_index_pair entry = a.frame.index[index];  // requested before the live count has arrived
     const uint32_t key = entry.key;
-    if (index >= a.frame.glob->g.ray_count) return;
+    if (index >= step_constant(&a.frame.glob->g.ray_count)) return;
     if (((key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) != RT_SH_MESH) return;
     RaySlot *ray = &a.frame.rays[entry.slot];
 
