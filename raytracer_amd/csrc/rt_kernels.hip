@@ -1136,11 +1136,18 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     }
     // save_queue (ray-tracer.cl:157-165)
     if (FRESH) {
-        // (a sample that enters nothing keeps queue_len and t_min as reset_ray set them, as below)
         if (k) {
             h.queue_len = k;
             h.t_min = head.pos;
+        } else if (LEAN && h.material_id == RT_SKY_GROUP && !(step_constant(&a.frame.glob->mode) & kModeTraceOnly)) {
+            // A camera ray that enters nothing: the sky's share goes to its pixel here and now (sky_shader,
+            // shader.cl:6-11, with the weight of one an unbounced camera ray has).  The slot is not written at all
+            // and nothing is read back from it: the free schedule keeps no state for a finished slot.
+            area_add(a.frame.area, h.pixel, 1.0f * 0.5f, 1.0f * 1.0f, 1.0f * 1.0f, 1.0f * 1.0f);
+            new_key = RT_SPAWN_GROUP;
+            return true;
         }
+        // (a sample that enters nothing keeps queue_len and t_min as reset_ray set them, as below)
         store_hot(ray, h);
     }
     if (k) {
