@@ -337,6 +337,21 @@ __device__ __forceinline__ uint32_t sky_or_light_shader(const ProcessArgs &a, Ra
     return RT_SPAWN_GROUP;
 }
 
+// Free schedule: the same for a ray whose visit has just emptied its queue, from what that visit holds in registers
+// (pixel and type; the weight comes from the slot unless it is the implied one).  True if `end_group` was the sky
+// or the light and the ray is done with; otherwise nothing has happened and the caller goes the general way.
+__device__ __forceinline__ bool finish_in_sky_or_light(const ProcessArgs &a, const RaySlot *ray, uint32_t end_group, uint32_t pixel,
+                                                       uint32_t type)
+{
+    const uint32_t shader = (end_group >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
+    if (shader != RT_SH_SKY && shader != RT_SH_LIGHT) return false;
+    if (step_constant(&a.frame.glob->mode) & kModeTraceOnly) return false;
+    const float4 w = ray_weight(ray, type);
+    const float cr = shader == RT_SH_LIGHT ? 1.0f : 0.5f;
+    area_add(a.frame.area, pixel, w.x * cr, w.y * 1.0f, w.z * 1.0f, w.w * 1.0f);
+    return true;
+}
+
 // A sample that bounces instead of being shaded (RT_SHADE_MIRROR: shader.cl:37-39; RT_SHADE_DIFFUSE: a
 // cosine-weighted direction, the normal plus a uniform point of the unit sphere, drawn by Marsaglia's
 // rejection method from hashed counters so that it only depends on seed, sample and bounce number).
@@ -377,18 +392,15 @@ __device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, HotRay h, float4
     return reset_ray<LEAN>(ray, h, root.group_id, root.local0, root.local1, RT_SKY_GROUP);
 }
 
+// mat_shader's direct-light part (shader.cl:20-40) for a ray whose hot fields and stored normal are at hand.
 template <bool LEAN>
-__device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color, uint32_t shading)
+__device__ __forceinline__ uint32_t direct_light_shader(RaySlot *ray, HotRay h, V3 stored_norm, float4 color)
 {
-    HotRay h = load_hot(ray);
-    if (shading & 15u) {
-        const uint32_t depth = h.type >> 8;
-        if (depth < ((shading >> 4) & 15u)) return bounce_shader<LEAN>(ray, h, color, shading, depth);
-    }
+    const RayHit root = ray->root;  // (asked for before anything is stored)
     const float l = 0.57735026f;
     const V3 light = v3(l, -l, l);
     const float alpha = 100, f0 = 0.04f;
-    const V3 dir = h.dir, norm = normalize(xyz(ray->norm));
+    const V3 dir = h.dir, norm = normalize(stored_norm);
     const V3 hvec = normalize(light - dir);
     float spec = (alpha + 2) / 8 * pow100(fmaxf(0.0f, dot(norm, hvec)));
     spec *= f0 + (1 - f0) * pow5(fmaxf(0.0f, -dot(dir, hvec)));
@@ -405,8 +417,18 @@ __device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color, uint3
     h.type = RT_RAY_SHADOW;
     h.start = h.start + dir * h.t_max;
     h.dir = light;
-    const RayHit root = ray->root;
     return reset_ray<LEAN>(ray, h, root.group_id, root.local0, root.local1, RT_LIGHT_GROUP);
+}
+
+template <bool LEAN>
+__device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color, uint32_t shading)
+{
+    HotRay h = load_hot(ray);
+    if (shading & 15u) {
+        const uint32_t depth = h.type >> 8;
+        if (depth < ((shading >> 4) & 15u)) return bounce_shader<LEAN>(ray, h, color, shading, depth);
+    }
+    return direct_light_shader<LEAN>(ray, h, xyz(ray->norm), color);
 }
 
 // Free schedule: a ray whose queue has emptied goes to its end group (sky, light, material or spawn).  The
@@ -554,7 +576,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
             end_group = RT_SPAWN_GROUP;
         } else {
             const uint32_t word = a.scene.tri[grp.y + hit_index];
-            sid = ray->sample_id;
+            sid = h.sample_id;
             const rt_vertex *vtx = a.scene.vtx + grp.x;
             const float4 n0 = *reinterpret_cast<const float4 *>(vtx[word & 0x3FF].norm);
             const float4 n1 = *reinterpret_cast<const float4 *>(vtx[(word >> 10) & 0x3FF].norm);
@@ -565,14 +587,16 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
         }
     }
     const float new_max = hit && !shadow ? best : h.t_max;
+    auto record_hit = [&]() {  // the record is the camera ray's hit: a sample that has bounced keeps it
+        if (h.type == RT_RAY_PRIMARY && sid < step_constant(&a.frame.glob->hit_capacity)) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
+    };
     auto commit_hit = [&](uint32_t len, float t_min) {  // what a hit leaves in the slot beside the queue
         if (shadow) {
             unsafeAtomicAdd(reinterpret_cast<float *>(&a.frame.area[h.pixel]) + 3, shadow_weight);
         } else {
             ray->norm = make_float4(nw.x, nw.y, nw.z, 0.0f);
             if (!LEAN) ray->orig = RayHit{best, head.group_id, head.local0, head.local1};
-            // the record is the camera ray's hit: a sample that has bounced keeps it
-            if (h.type == RT_RAY_PRIMARY && sid < step_constant(&a.frame.glob->hit_capacity)) a.frame.hits[sid] = rt_hit_record{best, head.group_id, head.local0, hit_index};
+            record_hit();
         }
         store_commit(ray, end_group, h.type, len, t_min, new_max);
     };
@@ -618,6 +642,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
             return next.group_id;
         }
         if (hit) commit_hit(queue_len, h.t_min);
+        else if (finish_in_sky_or_light(a, ray, end_group, h.pixel, h.type)) return RT_SPAWN_GROUP;
         return end_group;  // (the caller runs that group's shader right away: the head is not touched)
     }
 
@@ -1161,6 +1186,8 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
             ray->queue[0].local1 = 0;
         }
         new_key = end_group;
+        // (sky and light are dealt with here, where pixel and type are at hand: the caller's run_end_group would read them back)
+        if (LEAN && finish_in_sky_or_light(a, ray, end_group, h.pixel, h.type)) new_key = RT_SPAWN_GROUP;
     }
     AABB_STAMP(t_merged);
     AABB_STAMP_ADD(a.frame, 3, t_sorted, t_merged);
