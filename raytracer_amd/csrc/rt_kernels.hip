@@ -1051,8 +1051,10 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         if ((uint32_t)j < n) {
             const uint32_t bi = COOP ? c_idx[j] : s_idx[j][tid];
             cand_pos[j] = COOP ? c_pos[j] : s_pos[j][tid];
-            cand_group[j] = list[bi].group_id;
-            cand_local[j] = list[bi].local_id;
+            if (j < 4) {  // (the later candidates' ids are fetched below, and only by waves that have such candidates)
+                cand_group[j] = list[bi].group_id;
+                cand_local[j] = list[bi].local_id;
+            }
         }
     }
 #if defined(RT_STAMPS) && RT_STAMPS == 4
@@ -1156,6 +1158,17 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 #pragma unroll
     for (int j = 0; j < 4; j++) place_candidate(j);
     if (many_new) {
+        // Rarely needed, and sixteen registers the common case does without (held from the start they are spilled, and
+        // every reload from scratch in front of a store waits for the stores before it).
+#pragma unroll
+        for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) {
+            if ((uint32_t)j < n) {
+                const uint32_t bi = COOP ? c_idx[j] : s_idx[j][tid];
+                cand_group[j] = list[bi].group_id;
+                cand_local[j] = list[bi].local_id;
+            }
+        }
+        vector_loads_landed();
 #pragma unroll
         for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) place_candidate(j);
     }
