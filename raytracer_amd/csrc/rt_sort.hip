@@ -316,7 +316,10 @@ __global__ __launch_bounds__(kRankThreads) void k_fused_rank(const rt_index_pair
 #pragma unroll
     for (uint32_t i = 0; i < kPerThread; i++) {
         const uint32_t p = base + i * kRankThreads + tid;
-        keys[i] = p < n ? src[p].key : 0xFFFFFFFFu;
+        // (read whether or not it counts -- the tile lies inside the index -- so that the eight requests go out together:
+        // a load behind a branch gets a wait of its own)
+        const uint32_t key = src[p].key;
+        keys[i] = p < n ? key : 0xFFFFFFFFu;
     }
     for (uint32_t i = tid; i < groups; i += kRankThreads) s_group[i] = 0;
     __syncthreads();
@@ -383,15 +386,16 @@ __global__ __launch_bounds__(kGroupThreads) void k_fused_groups(DevGlobal *glob,
     __shared__ bool s_last;
     const uint32_t tid = threadIdx.x;
     const uint32_t g = blockIdx.x * kGroupThreads + tid;
-    const uint32_t groups = glob->g.group_count, n = glob->sort_count;
+    const uint32_t groups = step_constant(&glob->g.group_count), n = step_constant(&glob->sort_count);
+    const uint32_t warp_width = step_constant(&glob->warp_width);
     uint32_t main_count = 0, aligned = 0, tail = 0;
     rt_group_data grp = rt_group_data{{0, 0}, {0, 0}, {0, 0}};
     if (g < groups) {
         main_count = ghist[g];
-        ghist[g] = 0;  // ready for the next step
         grp = grp_data[g];
+        ghist[g] = 0;  // ready for the next step (stored after both loads have been asked for)
         const uint32_t total = main_count + grp.count[1];
-        tail = g != groups - 1 ? total % glob->warp_width : total;  // the last group is the dead-ray bin
+        tail = g != groups - 1 ? total % warp_width : total;  // the last group is the dead-ray bin
         aligned = total - tail;
     }
     uint32_t sum_main, sum_aligned, sum_tail;
