@@ -1133,6 +1133,20 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     // one wait here, and the stores below go out back to back.  Without it the compiler, which cannot tell across the
     // branches which loads are still under way, waits for all vector memory operations before each store's operands,
     // i.e. also for the store before.
+    // The later candidates' ids: where registers are not short (the kernel with two-byte places, the one-ray-per-wave
+    // kernel) they are asked for now, by the waves that need them; the main box kernel fetches them after the first four
+    // candidates have been placed (below).
+    constexpr bool ids_first = sizeof(PLACE) > 1 || COOP;
+    if (ids_first && many_new) {
+#pragma unroll
+        for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) {
+            if ((uint32_t)j < n) {
+                const uint32_t bi = COOP ? c_idx[j] : s_idx[j][tid];
+                cand_group[j] = list[bi].group_id;
+                cand_local[j] = list[bi].local_id;
+            }
+        }
+    }
     vector_loads_landed();
     if (some_old) {
 #pragma unroll
@@ -1160,15 +1174,17 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     if (many_new) {
         // Rarely needed, and sixteen registers the common case does without (held from the start they are spilled, and
         // every reload from scratch in front of a store waits for the stores before it).
+        if (!ids_first) {
 #pragma unroll
-        for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) {
-            if ((uint32_t)j < n) {
-                const uint32_t bi = COOP ? c_idx[j] : s_idx[j][tid];
-                cand_group[j] = list[bi].group_id;
-                cand_local[j] = list[bi].local_id;
+            for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) {
+                if ((uint32_t)j < n) {
+                    const uint32_t bi = COOP ? c_idx[j] : s_idx[j][tid];
+                    cand_group[j] = list[bi].group_id;
+                    cand_local[j] = list[bi].local_id;
+                }
             }
+            vector_loads_landed();
         }
-        vector_loads_landed();
 #pragma unroll
         for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) place_candidate(j);
     }
