@@ -682,7 +682,7 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
 //
 // More than 16 accepted boxes in a visit are rare (3 visits in 10,000 on the benchmark scene, 5 in a
 // million more than 24, the maximum seen is 36), so the kernel keeps 16 candidates per lane in LDS
-// (20 KB per block of 256) and holds the pending queue entries in registers only after the scan: seven
+// (20 KB per block of 256, plus 2 KB for the heads' local ids) and holds the pending queue entries in registers only after the scan: seven
 // waves per SIMD instead of the two that 64 candidates per lane would allow.  A lane that accepts a
 // 17th box leaves its ray untouched; k_process_aabb_big redoes that visit with a whole wave.
 
@@ -1235,7 +1235,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 // sends them through the scene root in the same launch, runs end-group shaders on the spot
 // (run_end_group) and carries the parked entries over, so no shading launch is needed.
 // PLACE: one byte per candidate's place in its list, or two for scenes with lists of more than 256 boxes
-// (24 instead of 20 KB of LDS per workgroup, i.e. six instead of seven workgroups per CU).
+// (24 instead of 20 KB of LDS per workgroup for the columns, i.e. six instead of seven workgroups per CU).
 template <bool FREE, typename PLACE>
 __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spill_list, float (*s_pos)[kAabbThreads],
                                              PLACE (*s_idx)[kAabbThreads], uint32_t head_lds)
