@@ -246,11 +246,9 @@ def main():
     resolve_and_gather()
     barrier()
     gather_ms = (time.perf_counter() - t_g) * 1e3  # one resolve + gather, measured outside the timed region too
-    t_h = time.perf_counter()
-    rt.draw_frame(host_band)                       # the same resolve plus the copy of the band to host memory
-    readback_ms = (time.perf_counter() - t_h) * 1e3
     keys = ("primary_spawned", "shadow_spawned", "box_tests", "tri_tests")
-    # the warm-up steps come last before the timed region (the frame read-back above leaves the GPU idle for milliseconds)
+    # the warm-up steps come last before the timed region; the frame read-back to host memory, which leaves the GPU idle
+    # for milliseconds, is measured after it
     rt.make_step(args.warmup)
     barrier()
     c0 = rt.counters()
@@ -261,6 +259,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     c1 = rt.counters()
+    t_h = time.perf_counter()
+    rt.draw_frame(host_band)                       # the same resolve plus the copy of the band to host memory
+    readback_ms = (time.perf_counter() - t_h) * 1e3
     d = {k: int(c1[k]) - int(c0[k]) for k in keys}
     if args.stage_timers == "timed":
         stage_ms, timed = rt.stage_times()
