@@ -63,6 +63,41 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return before + incl - v;
 }
 
+// The same for three values at once (one pair of barriers instead of three); s_wave3: [THREADS / 64][3].
+template <int THREADS>
+__device__ __forceinline__ void block_exclusive_scan3(const uint32_t (&v)[3], uint32_t (*s_wave3)[3], uint32_t (&before)[3],
+                                                      uint32_t (&total)[3])
+{
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl[3] = {v[0], v[1], v[2]};
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl[k], off, 64);
+            if (lane >= (uint32_t)off) incl[k] += o;
+        }
+    }
+    __syncthreads();  // s_wave3 may still be in use by a previous call
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) s_wave3[w][k] = incl[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t sum_before = 0, all = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < THREADS / 64; j++) {
+            const uint32_t t = s_wave3[j][k];
+            if (j < w) sum_before += t;
+            all += t;
+        }
+        total[k] = all;
+        before[k] = sum_before + incl[k] - v[k];
+    }
+}
+
 // Per-tile digit histogram of one pass: counts[digit * tiles + tile].
 template <uint32_t TILE, uint32_t THREADS>
 __global__ __launch_bounds__(THREADS) void k_sort_count(const rt_index_pair *src, const uint32_t *n_ptr,
@@ -382,7 +417,7 @@ __global__ __launch_bounds__(kRankThreads) void k_fused_rank(const rt_index_pair
 __global__ __launch_bounds__(kGroupThreads) void k_fused_groups(DevGlobal *glob, rt_group_data *grp_data, uint32_t *ghist,
                                                                  CompactWorkspace ws, uint32_t *block_main, uint32_t group_blocks)
 {
-    __shared__ uint32_t s_wave[kGroupThreads / 64];
+    __shared__ uint32_t s_wave3[kGroupThreads / 64][3];
     __shared__ bool s_last;
     const uint32_t tid = threadIdx.x;
     const uint32_t g = blockIdx.x * kGroupThreads + tid;
@@ -398,10 +433,11 @@ __global__ __launch_bounds__(kGroupThreads) void k_fused_groups(DevGlobal *glob,
         tail = g != groups - 1 ? total % warp_width : total;  // the last group is the dead-ray bin
         aligned = total - tail;
     }
-    uint32_t sum_main, sum_aligned, sum_tail;
-    const uint32_t before_main = block_exclusive_scan<kGroupThreads>(main_count, s_wave, sum_main);
-    const uint32_t before_aligned = block_exclusive_scan<kGroupThreads>(aligned, s_wave, sum_aligned);
-    const uint32_t before_tail = block_exclusive_scan<kGroupThreads>(tail, s_wave, sum_tail);
+    const uint32_t mine[3] = {main_count, aligned, tail};
+    uint32_t before[3], totals[3];
+    block_exclusive_scan3<kGroupThreads>(mine, s_wave3, before, totals);
+    const uint32_t before_main = before[0], before_aligned = before[1], before_tail = before[2];
+    const uint32_t sum_main = totals[0], sum_aligned = totals[1], sum_tail = totals[2];
     if (g < groups) {
         ws.move[g] = GroupMove{before_main, grp.offset[1] - main_count, tail, before_aligned, before_tail, {0, 0, 0}};
         grp_data[g].base[1] = grp.offset[1] - main_count;
@@ -425,7 +461,7 @@ __global__ __launch_bounds__(kGroupThreads) void k_fused_groups(DevGlobal *glob,
         const uint2 sums = in ? ws.block_sums[first + tid] : make_uint2(0, 0);
         const uint32_t v[3] = {in ? block_main[first + tid] : 0u, sums.x, sums.y};
         uint32_t excl[3], all[3];
-        for (int k = 0; k < 3; k++) excl[k] = block_exclusive_scan<kGroupThreads>(v[k], s_wave, all[k]);
+        block_exclusive_scan3<kGroupThreads>(v, s_wave3, excl, all);
         if (in) {
             block_main[first + tid] = carry[0] + excl[0];
             ws.block_sums[first + tid] = make_uint2(carry[1] + excl[1], carry[2] + excl[2]);
