@@ -138,6 +138,17 @@ typedef struct {
  * reproduces the reference's make_step exactly. */
 #define RT_FLAG_FREE_SCHEDULE 1u
 
+/* RT_FLAG_ARITH_MAD: multiply-adds are fused, as the reference asks of its OpenCL compiler with -cl-mad-enable
+ * (main.cpp:253).  Without the flag every product and sum is rounded on its own.  With it, one rounding is
+ * saved at stated places and nowhere else: the three-term sums of products of `transform` (shader.cl:63-65), of
+ * the normal's interpolation and rotation (shader.cl:137, ray-tracer.cl:180) and of every dot product are
+ * fma(c, w, fma(b, v, a*u)); a component p*q - r*s of a cross product is fma(p, q, -(r*s)); start + dir*t and the
+ * camera ray's top_left + dx*x + dy*y are chains of fma; and the slab test's (corner - start) * inv_dir
+ * (shader.cl:86-87) is fma(corner, inv_dir, -(start*inv_dir)) with the second product taken once per ray.
+ * Division, sqrt, pow and all comparisons are the same in both modes.  A sample's hit can differ between the modes
+ * where a ray grazes an edge; within a mode every result is reproducible bit for bit. */
+#define RT_FLAG_ARITH_MAD 2u
+
 /* Shading beyond the reference's one shadow ray per sample, also in rt_config.flags: bits 8-11 say what a
  * material group does with a sample that has hit it, bits 12-15 how many times (bounces), bits 16-31 seed
  * the random directions.  After `bounces` bounces, and always with RT_SHADE_REFERENCE, a hit is shaded as

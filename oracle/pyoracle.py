@@ -55,6 +55,9 @@ def lib():
         o.orc_get_work.argtypes = [vp, vp]
         o.orc_trace_closest.restype = C.c_int
         o.orc_trace_closest.argtypes = [vp, vp, u32, vp]
+        o.orc_camera_rays.argtypes = [vp, vp, u32, vp]
+        o.orc_init_frame_samples.restype = C.c_int
+        o.orc_init_frame_samples.argtypes = [vp, vp, u32]
         o.orc_sort_pairs.argtypes = [vp, vp, u32, u32, u32]
         o.orc_sort_block_index.restype = u32
         o.orc_sort_block_index.argtypes = [u32, u32]
@@ -75,10 +78,10 @@ def _view(ptr, count, dtype):
 class Oracle:
     """The reference pipeline on the CPU: same calls as raytracer_amd.RayTracer."""
 
-    def __init__(self, scene, warp_width=32, sample_limit=0, hit_capacity=0, threads=1, shading=0):
+    def __init__(self, scene, warp_width=32, sample_limit=0, hit_capacity=0, threads=1, shading=0, mad=False):
         self.scene = scene
         cfg = Config(0, scene.width, scene.height, scene.pool_size, warp_width, sample_limit, hit_capacity,
-                     scene.row_offset, shading)
+                     scene.row_offset, shading | (2 if mad else 0))  # RT_FLAG_ARITH_MAD
         self.h = lib().orc_create(C.byref(cfg))
         if not self.h:
             raise RuntimeError("orc_create failed")
@@ -105,6 +108,20 @@ class Oracle:
 
     def step(self, n=1):
         lib().orc_step(self.h, n)
+
+    def camera_rays(self, samples):
+        """The camera rays of the given sample numbers, as init_ray sets them up."""
+        samples = np.ascontiguousarray(samples, dtype=np.uint32)
+        rays = np.zeros(len(samples), L.ray_dtype)
+        lib().orc_camera_rays(self.h, samples.ctypes.data, len(samples), rays.ctypes.data)
+        return rays
+
+    def init_frame_samples(self, samples):
+        """A frame in which slot i runs sample number samples[i] and nothing else is ever started."""
+        samples = np.ascontiguousarray(samples, dtype=np.uint32)
+        rc = lib().orc_init_frame_samples(self.h, samples.ctypes.data, len(samples))
+        if rc:
+            raise RuntimeError(f"orc_init_frame_samples failed: {rc}")
 
     def set_warp_width(self, w):
         lib().orc_set_warp_width(self.h, w)

@@ -43,6 +43,7 @@ struct orc_ctx {
     size_t n_groups, n_mat, n_aabb, n_vtx, n_tri;
     uint32_t *sample_id;
     uint32_t shading; /* bits 8-31 of rt_config.flags: mode, bounces, seed */
+    int mad;          /* RT_FLAG_ARITH_MAD: multiply-adds fused at the places the *_m helpers name */
     rt_hit_record *hits;
     rt_counters counters;
     orc_work work;
@@ -63,7 +64,40 @@ static inline v3 v3_cross(v3 a, v3 b)
 {
     return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-static inline v3 v3_normalize(v3 a) { return v3_scale(a, 1.0f / sqrtf(v3_dot(a, a))); }
+
+/* The two arithmetic modes.  mad == 0: every product and sum rounded on its own (the header's contract).  mad != 0
+ * (RT_FLAG_ARITH_MAD, the reference's -cl-mad-enable, main.cpp:253): a product that feeds a sum is fused with it
+ * (fmaf, one rounding) at exactly the places these helpers are used; everything else is as in the other mode. */
+static inline float mad1(int mad, float a, float b, float c) { return mad ? fmaf(a, b, c) : a * b + c; }
+/* dot(a, b) = (a.x*b.x + a.y*b.y) + a.z*b.z */
+static inline float v3_dot_m(int mad, v3 a, v3 b)
+{
+    return mad ? fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)) : v3_dot(a, b);
+}
+/* cross(a, b), each component p*q - r*s */
+static inline v3 v3_cross_m(int mad, v3 a, v3 b)
+{
+    if (!mad) return v3_cross(a, b);
+    return v3_make(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+/* a*s + b */
+static inline v3 v3_madd_m(int mad, v3 a, float s, v3 b)
+{
+    return v3_make(mad1(mad, a.x, s, b.x), mad1(mad, a.y, s, b.y), mad1(mad, a.z, s, b.z));
+}
+/* (a*s + b*t) + c*u */
+static inline v3 v3_lin3_m(int mad, v3 a, float s, v3 b, float t, v3 c, float u)
+{
+    if (!mad) return v3_add(v3_add(v3_scale(a, s), v3_scale(b, t)), v3_scale(c, u));
+    return v3_make(fmaf(c.x, u, fmaf(b.x, t, a.x * s)), fmaf(c.y, u, fmaf(b.y, t, a.y * s)), fmaf(c.z, u, fmaf(b.z, t, a.z * s)));
+}
+static inline v3 v3_normalize_m(int mad, v3 a) { return v3_scale(a, 1.0f / sqrtf(v3_dot_m(mad, a, a))); }
+/* the direction of a camera ray: (top_left + dx*x) + dy*y, normalised (ray-tracer.cl:64-68) */
+static inline v3 camera_dir(int mad, const rt_camera *cam, float x, float y)
+{
+    const v3 tl = v3_load(cam->top_left), dx = v3_load(cam->dx), dy = v3_load(cam->dy);
+    return v3_normalize_m(mad, v3_madd_m(mad, dy, y, v3_madd_m(mad, dx, x, tl)));
+}
 static inline v3 v3_min(v3 a, v3 b) { return v3_make(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
 static inline v3 v3_max(v3 a, v3 b) { return v3_make(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
 
@@ -129,8 +163,7 @@ static uint32_t init_ray(orc_ctx *c, uint32_t slot, uint32_t sample)
     ray->weight[0] = ray->weight[1] = ray->weight[2] = ray->weight[3] = 1;
     ray->type = RT_RAY_PRIMARY;
     v3_store(ray->start_min, v3_load(cam->eye));
-    v3 dir = v3_add(v3_add(v3_load(cam->top_left), v3_scale(v3_load(cam->dx), x)), v3_scale(v3_load(cam->dy), y));
-    v3_store(ray->dir_max, v3_normalize(dir));
+    v3_store(ray->dir_max, camera_dir(c->mad, cam, x, y));
     ray->root.group_id = cam->root_group;
     ray->root.local_id[0] = cam->root_local;
     ray->root.local_id[1] = 0;
@@ -173,14 +206,14 @@ static float uniform01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0
  * (rt_config.flags, RT_FLAG_SHADING).  Mirror: the lines the reference left commented out, shader.cl:37-39.
  * Diffuse: normal (turned towards the incoming side) plus a uniform point of the unit sphere (Marsaglia's
  * rejection method on hashed counters), normalised; weight times the material colour. */
-static uint32_t bounce_shader(rt_ray_queue *ray, const rt_mat_shader *shader, uint32_t shading, uint32_t depth, uint32_t sample)
+static uint32_t bounce_shader(rt_ray_queue *ray, const rt_mat_shader *shader, uint32_t shading, uint32_t depth, uint32_t sample, int mad)
 {
-    const v3 dir = v3_load(ray->dir_max), norm = v3_normalize(v3_load(ray->norm));
+    const v3 dir = v3_load(ray->dir_max), norm = v3_normalize_m(mad, v3_load(ray->norm));
     v3 out;
     if ((shading & 15u) == RT_SHADE_MIRROR) {
-        out = v3_sub(dir, v3_scale(norm, 2 * v3_dot(dir, norm)));
+        out = v3_madd_m(mad, norm, -(2 * v3_dot_m(mad, dir, norm)), dir); /* dir - norm * (2 dot(dir, norm)) */
     } else {
-        const v3 up = v3_dot(dir, norm) > 0 ? v3_make(-norm.x, -norm.y, -norm.z) : norm;
+        const v3 up = v3_dot_m(mad, dir, norm) > 0 ? v3_make(-norm.x, -norm.y, -norm.z) : norm;
         const uint32_t base = hash32((shading >> 8) ^ sample * 0x9E3779B9u ^ depth * 0x85EBCA6Bu);
         float x1 = 0, x2 = 0, s = 0;
         for (uint32_t k = 0; k < 8; k++) {
@@ -190,37 +223,37 @@ static uint32_t bounce_shader(rt_ray_queue *ray, const rt_mat_shader *shader, ui
         }
         const float r = 2 * sqrtf(1 - s);
         const v3 v = v3_add(up, v3_make(x1 * r, x2 * r, 1 - 2 * s));
-        const float len2 = v3_dot(v, v);
+        const float len2 = v3_dot_m(mad, v, v);
         out = len2 > 1e-12f ? v3_scale(v, 1.0f / sqrtf(len2)) : up;
         ray->weight[0] *= shader->color[0]; ray->weight[1] *= shader->color[1]; ray->weight[2] *= shader->color[2];
     }
     ray->type = RT_RAY_PRIMARY | (depth + 1) << 8;
-    v3_store(ray->start_min, v3_add(v3_load(ray->start_min), v3_scale(dir, ray->dir_max[3])));
+    v3_store(ray->start_min, v3_madd_m(mad, dir, ray->dir_max[3], v3_load(ray->start_min)));
     v3_store(ray->dir_max, out);
     return reset_ray(ray, ray->root.group_id, ray->root.local_id, RT_SKY_GROUP);
 }
 
 /* shader.cl:20-35 */
-static uint32_t mat_shader(rt_ray_queue *ray, const rt_mat_shader *shader, uint32_t shading, uint32_t sample)
+static uint32_t mat_shader(rt_ray_queue *ray, const rt_mat_shader *shader, uint32_t shading, uint32_t sample, int mad)
 {
     if (shading & 15u) {
         const uint32_t depth = ray->type >> 8;
-        if (depth < ((shading >> 4) & 15u)) return bounce_shader(ray, shader, shading, depth, sample);
+        if (depth < ((shading >> 4) & 15u)) return bounce_shader(ray, shader, shading, depth, sample, mad);
     }
     const float l = 0.57735026f; /* normalize((1,-1,1)) */
     const v3 light = v3_make(l, -l, l);
     const float alpha = 100, f0 = 0.04f;
-    const v3 dir = v3_load(ray->dir_max), norm = v3_normalize(v3_load(ray->norm));
-    const v3 hvec = v3_normalize(v3_sub(light, dir));
-    float spec = (alpha + 2) / 8 * pow100(fmaxf(0.0f, v3_dot(norm, hvec)));
-    spec *= f0 + (1 - f0) * pow5(fmaxf(0.0f, -v3_dot(dir, hvec)));
-    const float lambert = fmaxf(0.0f, v3_dot(light, norm));
+    const v3 dir = v3_load(ray->dir_max), norm = v3_normalize_m(mad, v3_load(ray->norm));
+    const v3 hvec = v3_normalize_m(mad, v3_sub(light, dir));
+    float spec = (alpha + 2) / 8 * pow100(fmaxf(0.0f, v3_dot_m(mad, norm, hvec)));
+    spec *= f0 + (1 - f0) * pow5(fmaxf(0.0f, -v3_dot_m(mad, dir, hvec)));
+    const float lambert = fmaxf(0.0f, v3_dot_m(mad, light, norm));
     const float sw = spec * shader->color[3];
     const v3 color = v3_scale(v3_make(shader->color[0] + sw, shader->color[1] + sw, shader->color[2] + sw), lambert);
 
     ray->weight[0] *= color.x; ray->weight[1] *= color.y; ray->weight[2] *= color.z; ray->weight[3] *= 1.0f;
     ray->type = RT_RAY_SHADOW;
-    v3_store(ray->start_min, v3_add(v3_load(ray->start_min), v3_scale(dir, ray->dir_max[3])));
+    v3_store(ray->start_min, v3_madd_m(mad, dir, ray->dir_max[3], v3_load(ray->start_min)));
     v3_store(ray->dir_max, light);
     return reset_ray(ray, ray->root.group_id, ray->root.local_id, RT_LIGHT_GROUP);
 }
@@ -228,7 +261,7 @@ static uint32_t mat_shader(rt_ray_queue *ray, const rt_mat_shader *shader, uint3
 typedef struct { v3 start, dir; float min, max; } local_ray;
 
 /* shader.cl:43-73.  mat[0..2] = columns of the rotation, mat[3] = translation. */
-static void transform(uint32_t group_id, const rt_ray_queue *ray, local_ray *res, v3 mat[4], const rt_matrix *mat_list)
+static void transform(uint32_t group_id, const rt_ray_queue *ray, local_ray *res, v3 mat[4], const rt_matrix *mat_list, int mad)
 {
     res->start = v3_load(ray->start_min); res->min = ray->start_min[3];
     res->dir = v3_load(ray->dir_max);     res->max = ray->dir_max[3];
@@ -244,9 +277,9 @@ static void transform(uint32_t group_id, const rt_ray_queue *ray, local_ray *res
         mat[3] = v3_make(m->x[3], m->y[3], m->z[3]);
         const v3 rel = v3_sub(res->start, mat[3]);
         const v3 mx = v3_load(m->x), my = v3_load(m->y), mz = v3_load(m->z);
-        res->start = v3_add(v3_add(v3_scale(mx, rel.x), v3_scale(my, rel.y)), v3_scale(mz, rel.z));
+        res->start = v3_lin3_m(mad, mx, rel.x, my, rel.y, mz, rel.z);
         const v3 d = res->dir;
-        res->dir = v3_add(v3_add(v3_scale(mx, d.x), v3_scale(my, d.y)), v3_scale(mz, d.z));
+        res->dir = v3_lin3_m(mad, mx, d.x, my, d.y, mz, d.z);
         break;
     }
     default: /* tr_none, tr_affine: nothing (shader.cl:69-71) */
@@ -256,17 +289,23 @@ static void transform(uint32_t group_id, const rt_ray_queue *ray, local_ray *res
 }
 
 /* shader.cl:76-101 */
+/* With mad, (corner - start) * inv_dir is evaluated as fma(corner, inv_dir, -(start * inv_dir)): the second
+ * product once per ray, one fused operation per corner coordinate. */
 static uint32_t aabb_shader(const local_ray *ray, const rt_aabb_shader *shader, const rt_ray_hit *cur, rt_ray_hit *hit,
-                            const rt_aabb *aabb)
+                            const rt_aabb *aabb, int mad)
 {
     aabb += shader->aabb_offs;
     const v3 inv_dir = v3_make(1 / ray->dir.x, 1 / ray->dir.y, 1 / ray->dir.z);
     const uint32_t n = shader->aabb_count;
     uint32_t hit_count = 0;
     const int flag0 = (shader->flags & RT_F_LOCAL0) != 0, flag1 = (shader->flags & RT_F_LOCAL1) != 0;
+    const v3 neg = v3_make(-(ray->start.x * inv_dir.x), -(ray->start.y * inv_dir.y), -(ray->start.z * inv_dir.z));
     for (uint32_t i = 0; i < n; i++) {
-        const v3 pos1 = v3_mul(v3_sub(v3_load(aabb[i].min), ray->start), inv_dir);
-        const v3 pos2 = v3_mul(v3_sub(v3_load(aabb[i].max), ray->start), inv_dir);
+        const v3 lo = v3_load(aabb[i].min), hi = v3_load(aabb[i].max);
+        const v3 pos1 = mad ? v3_make(fmaf(lo.x, inv_dir.x, neg.x), fmaf(lo.y, inv_dir.y, neg.y), fmaf(lo.z, inv_dir.z, neg.z))
+                            : v3_mul(v3_sub(lo, ray->start), inv_dir);
+        const v3 pos2 = mad ? v3_make(fmaf(hi.x, inv_dir.x, neg.x), fmaf(hi.y, inv_dir.y, neg.y), fmaf(hi.z, inv_dir.z, neg.z))
+                            : v3_mul(v3_sub(hi, ray->start), inv_dir);
         const v3 pos_min = v3_min(pos1, pos2), pos_max = v3_max(pos1, pos2);
         const float t_min = fmaxf(fmaxf(pos_min.x, pos_min.y), pos_min.z);
         const float t_max = fminf(fminf(pos_max.x, pos_max.y), pos_max.z);
@@ -283,7 +322,7 @@ static uint32_t aabb_shader(const local_ray *ray, const rt_aabb_shader *shader, 
 
 /* shader.cl:115-139.  Returns material id or 0xFFFFFFFF; norm_pos = (object-space normal, t). */
 static uint32_t mesh_shader(const local_ray *ray, const rt_mesh_shader *shader, float norm_pos[4], const rt_vertex *vtx,
-                            const uint32_t *tri, uint32_t *hit_tri)
+                            const uint32_t *tri, uint32_t *hit_tri, int mad)
 {
     vtx += shader->vtx_offs;
     tri += shader->tri_offs;
@@ -296,20 +335,19 @@ static uint32_t mesh_shader(const local_ray *ray, const rt_mesh_shader *shader, 
         v3 r = v3_load(vtx[i0].pos);
         const v3 p = v3_sub(v3_load(vtx[i1].pos), r), q = v3_sub(v3_load(vtx[i2].pos), r);
         r = v3_sub(r, ray->start);
-        const v3 nrm = v3_cross(p, q);
-        float w = v3_dot(ray->dir, nrm);
+        const v3 nrm = v3_cross_m(mad, p, q);
+        float w = v3_dot_m(mad, ray->dir, nrm);
         w = 1 / w;
-        const float t = v3_dot(r, nrm) * w;
+        const float t = v3_dot_m(mad, r, nrm) * w;
         if (!(t > ray->min && t < norm_pos[3])) continue;
-        const v3 dr = v3_cross(ray->dir, r);
-        const float u = -v3_dot(q, dr) * w, v = v3_dot(p, dr) * w;
+        const v3 dr = v3_cross_m(mad, ray->dir, r);
+        const float u = -v3_dot_m(mad, q, dr) * w, v = v3_dot_m(mad, p, dr) * w;
         if (!(u >= 0 && v >= 0 && u + v <= 1)) continue;
         norm_pos[3] = t; hit_u = u; hit_v = v; hit_index = i;
     }
     if (hit_index == 0xFFFFFFFFu) return 0xFFFFFFFFu;
     const uint32_t i0 = tri[hit_index] & 0x3FF, i1 = (tri[hit_index] >> 10) & 0x3FF, i2 = (tri[hit_index] >> 20) & 0x3FF;
-    const v3 nn = v3_add(v3_add(v3_scale(v3_load(vtx[i0].norm), 1 - hit_u - hit_v), v3_scale(v3_load(vtx[i1].norm), hit_u)),
-                         v3_scale(v3_load(vtx[i2].norm), hit_v));
+    const v3 nn = v3_lin3_m(mad, v3_load(vtx[i0].norm), 1 - hit_u - hit_v, v3_load(vtx[i1].norm), hit_u, v3_load(vtx[i2].norm), hit_v);
     norm_pos[0] = nn.x; norm_pos[1] = nn.y; norm_pos[2] = nn.z;
     *hit_tri = hit_index;
     return shader->material_id;
@@ -363,7 +401,7 @@ static void process_one(orc_ctx *c, uint32_t index, rt_index_pair *ray_index, or
 
     local_ray cur;
     v3 mat[4];
-    transform(group_id, ray, &cur, mat, c->mat_list);
+    transform(group_id, ray, &cur, mat, c->mat_list, c->mad);
     rt_ray_hit hit[RT_MAX_QUEUE_LEN], new_hit[RT_MAX_HITS];
     uint32_t queue_len;
 
@@ -382,13 +420,13 @@ static void process_one(orc_ctx *c, uint32_t index, rt_index_pair *ray_index, or
 
     case RT_SH_MATERIAL:
         if (c->mode & ORC_TRACE_ONLY) { group_id = ray->queue[0].group_id = dead; break; }
-        group_id = mat_shader(ray, &grp->material, c->shading, c->sample_id[offs]);
+        group_id = mat_shader(ray, &grp->material, c->shading, c->sample_id[offs], c->mad);
         work->shade_calls++;
         work->shadows++;
         break;
 
     case RT_SH_AABB: { /* insert_hits, ray-tracer.cl:205-231 */
-        const uint32_t n = aabb_shader(&cur, &grp->aabb, &ray->queue[0], new_hit, c->aabb);
+        const uint32_t n = aabb_shader(&cur, &grp->aabb, &ray->queue[0], new_hit, c->aabb, c->mad);
         if (c->threads <= 1) c->hit_hist[n]++;
         work->box_tests += grp->aabb.aabb_count;
         work->node_visits++;
@@ -426,7 +464,7 @@ static void process_one(orc_ctx *c, uint32_t index, rt_index_pair *ray_index, or
     case RT_SH_MESH: {
         float norm_pos[4];
         uint32_t hit_tri = 0;
-        uint32_t material_id = mesh_shader(&cur, &grp->mesh, norm_pos, c->vtx, c->tri, &hit_tri);
+        uint32_t material_id = mesh_shader(&cur, &grp->mesh, norm_pos, c->vtx, c->tri, &hit_tri, c->mad);
         work->tri_tests += grp->mesh.tri_count;
         work->node_visits++;
         if (material_id == 0xFFFFFFFFu) { /* miss: pop the head, ray-tracer.cl:154-165 */
@@ -440,7 +478,7 @@ static void process_one(orc_ctx *c, uint32_t index, rt_index_pair *ray_index, or
             area_add(c, ray->pixel, 0, 0, 0, ray->weight[3]);
             material_id = RT_SPAWN_GROUP;
         } else {
-            const v3 nw = v3_add(v3_add(v3_scale(mat[0], norm_pos[0]), v3_scale(mat[1], norm_pos[1])), v3_scale(mat[2], norm_pos[2]));
+            const v3 nw = v3_lin3_m(c->mad, mat[0], norm_pos[0], mat[1], norm_pos[1], mat[2], norm_pos[2]);
             v3_store(ray->norm, nw);
             ray->dir_max[3] = norm_pos[3];
             ray->orig.pos = norm_pos[3];
@@ -779,6 +817,7 @@ orc_ctx *orc_create(const rt_config *cfg)
     c->hit_capacity = cfg->hit_capacity;
     c->row_offset = cfg->row_offset;
     c->shading = cfg->flags >> 8;
+    c->mad = (cfg->flags & RT_FLAG_ARITH_MAD) != 0;
     c->threads = 1;
     c->area = calloc((size_t)c->area_size * 4, sizeof(float));
     c->ray_list = calloc(c->pool, sizeof(rt_ray_queue));
@@ -839,6 +878,53 @@ uint32_t orc_pool_size(orc_ctx *c) { return c->pool; }
 void orc_get_counters(orc_ctx *c, rt_counters *dst) { *dst = c->counters; }
 void orc_get_work(orc_ctx *c, orc_work *dst) { *dst = c->work; }
 void orc_get_hit_histogram(orc_ctx *c, uint64_t *dst) { memcpy(dst, c->hit_hist, sizeof(c->hit_hist)); }
+
+/* The camera ray of sample number `sample`, as init_ray sets it up (ray-tracer.cl:56-74): for tests that trace a
+ * frame's own samples through orc_trace_closest. */
+void orc_camera_rays(orc_ctx *c, const uint32_t *samples, uint32_t n, rt_ray *out)
+{
+    const rt_camera *cam = &c->global.cam;
+    const uint32_t total = cam->width * cam->height;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t sub[2];
+        orc_deinterleave(samples[i] / total, sub);
+        const uint32_t pixel = samples[i] % total;
+        const float x = (float)(pixel % cam->width) + orc_subpixel(sub[0]);
+        const float y = (float)(pixel / cam->width + c->row_offset) + orc_subpixel(sub[1]);
+        v3_store(out[i].start_min, v3_load(cam->eye));
+        out[i].start_min[3] = 0.001f;
+        v3_store(out[i].dir_max, camera_dir(c->mad, cam, x, y));
+        out[i].dir_max[3] = INFINITY;
+    }
+}
+
+/* Starts a frame in which slot i runs sample number samples[i] (i < n) and every other slot is parked in the
+ * dead-ray bin; no further samples are started (finished slots find the sample range used up).  Needs a
+ * sample_limit above every id given.  The frame then advances with orc_step like any other: shading, shadow
+ * rays and bounces included.  Used to follow single samples, e.g. those that never finish. */
+int orc_init_frame_samples(orc_ctx *c, const uint32_t *samples, uint32_t n)
+{
+    if (n > c->pool || !c->grp_list || !c->sample_limit) return RT_ERR_INVALID_VALUE;
+    for (uint32_t i = 0; i < n; i++)
+        if (samples[i] >= c->sample_limit) return RT_ERR_INVALID_VALUE;
+    for (uint32_t g = 0; g < c->group_count; g++) { c->grp_data[g].count[1] = 0; c->grp_data[g].offset[1] = 0xFFFFFFFFu; }
+    c->global.ray_count = c->pool;
+    const uint32_t dead = c->group_count - 1;
+    for (uint32_t index = 0; index < c->pool; index++) {
+        c->ray_index[0][index].key = index < n ? init_ray(c, index, samples[index]) : dead;
+        c->ray_index[0][index].slot = index;
+    }
+    c->global.pixel_offset = c->sample_limit; c->global.pixel_count = 0;
+    memset(c->area, 0, (size_t)c->area_size * 4 * sizeof(float));
+    memset(&c->counters, 0, sizeof(c->counters));
+    memset(&c->work, 0, sizeof(c->work));
+    c->counters.primary_spawned = c->work.spawned = n;
+    rt_index_pair *sorted = malloc((size_t)c->pool * sizeof(rt_index_pair));
+    orc_sort_pairs(c->ray_index[0], sorted, c->pool, c->pool, c->group_count);
+    orc_compact_groups(sorted, c->ray_index[0], c->pool, c->grp_data, &c->global, c->warp_width);
+    free(sorted);
+    return RT_OK;
+}
 
 int orc_trace_closest(orc_ctx *c, const rt_ray *rays, uint32_t n_rays, rt_hit_record *hits)
 {

@@ -17,6 +17,8 @@
  *   dot(a,b)      = (a.x*b.x + a.y*b.y) + a.z*b.z
  *   normalize(v)  = v * (1 / sqrt(dot(v,v)))
  *   pow(x, 100), pow(x, 5) = products of repeated squares (integer exponents, shader.cl:26-27)
+ * With RT_FLAG_ARITH_MAD in rt_config.flags the multiply-adds named in include/rt_hip.h are fused (fmaf),
+ * as the reference's -cl-mad-enable allows (main.cpp:253); nothing else changes.
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
@@ -67,6 +69,11 @@ void orc_get_hit_histogram(orc_ctx *ctx, uint64_t *dst);
 /* Loads caller rays as primary samples 0..n-1 (replacing init_rays) and steps with granularity 1
  * until every ray has left the hierarchy; mirrors rt_trace_closest. */
 int orc_trace_closest(orc_ctx *ctx, const rt_ray *rays, uint32_t n_rays, rt_hit_record *hits);
+
+/* Camera rays of the given sample numbers, as init_ray builds them (ray-tracer.cl:56-74). */
+void orc_camera_rays(orc_ctx *ctx, const uint32_t *samples, uint32_t n, rt_ray *out);
+/* Starts a frame whose first n slots run the given sample numbers and nothing else; see rt_oracle.c. */
+int orc_init_frame_samples(orc_ctx *ctx, const uint32_t *samples, uint32_t n);
 
 /* ---- single stages on caller data ---- */
 

@@ -154,9 +154,11 @@ bool slurp(const char *file, std::vector<char> &text)
 // bytes.  Parsing the ASCII text of a large mesh with strtof is the slow part of start-up (the
 // reference's fscanf loop, model.cpp:162-190, is slower still); reading the file and hashing it is
 // not.  The cache lives in $RT_MESH_CACHE, or in rt_mesh_cache_<uid> under $TMPDIR or /tmp; an empty
-// RT_MESH_CACHE switches it off.  A cache file that does not match in every header field is ignored.
+// RT_MESH_CACHE switches it off.  A cache file that does not match in every header field, or whose size is not
+// exactly what its counts say, is ignored.  The directory is only used when it belongs to this user and nobody
+// else may write to it (a directory another local user created under /tmp could hold planted files).
 struct CacheHeader {
-    char magic[8];  // "RTMESH1"
+    char magic[8];  // "RTMESH2": version of this layout and of the parser that filled it
     uint64_t hash, file_size, n_vtx, n_tri;
 };
 
@@ -182,6 +184,8 @@ std::string cache_path(const char *file, uint64_t hash)
         base = std::string(tmp && *tmp ? tmp : "/tmp") + "/rt_mesh_cache_" + std::to_string((unsigned long)getuid());
     }
     ::mkdir(base.c_str(), 0700);
+    struct stat st;
+    if (::lstat(base.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return "";
     std::string name = file;
     const size_t slash = name.find_last_of('/');
     if (slash != std::string::npos) name = name.substr(slash + 1);
@@ -196,14 +200,23 @@ bool read_cache(const std::string &path, uint64_t hash, uint64_t file_size, std:
     FILE *in = std::fopen(path.c_str(), "rb");
     if (!in) return false;
     CacheHeader h;
-    bool ok = std::fread(&h, sizeof(h), 1, in) == 1 && !std::memcmp(h.magic, "RTMESH1", 8) && h.hash == hash &&
+    struct stat st;
+    bool ok = ::fstat(fileno(in), &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() &&
+              std::fread(&h, sizeof(h), 1, in) == 1 && !std::memcmp(h.magic, "RTMESH2", 8) && h.hash == hash &&
               h.file_size == file_size && h.n_vtx && h.n_tri && h.n_vtx < (1ull << 32) && h.n_tri < (1ull << 32);
+    // the counts must account for the file's size exactly before anything is sized by them
+    ok = ok && uint64_t(st.st_size) == sizeof(h) + h.n_vtx * sizeof(Vec3) + h.n_tri * sizeof(faces[0]);
     if (ok) {
-        positions.resize(h.n_vtx);
-        faces.resize(h.n_tri);
+        try {
+            positions.resize(h.n_vtx);
+            faces.resize(h.n_tri);
+        } catch (const std::bad_alloc &) {
+            ok = false;
+        }
+    }
+    if (ok)
         ok = std::fread(positions.data(), sizeof(Vec3), h.n_vtx, in) == h.n_vtx &&
              std::fread(faces.data(), sizeof(faces[0]), h.n_tri, in) == h.n_tri && std::fgetc(in) == EOF;
-    }
     std::fclose(in);
     return ok;
 }
@@ -215,7 +228,7 @@ void write_cache(const std::string &path, uint64_t hash, uint64_t file_size, con
     FILE *out = std::fopen(tmp.c_str(), "wb");
     if (!out) return;
     CacheHeader h;
-    std::memcpy(h.magic, "RTMESH1", 8);
+    std::memcpy(h.magic, "RTMESH2", 8);
     h.hash = hash;
     h.file_size = file_size;
     h.n_vtx = positions.size();
@@ -229,6 +242,17 @@ void write_cache(const std::string &path, uint64_t hash, uint64_t file_size, con
 }  // namespace
 
 bool Model::load(const char *file)
+{
+    try {
+        return load_file(file);
+    } catch (const std::bad_alloc &) {  // a header that promises more than memory holds: a failed load, not a crash
+        pos_.clear();
+        faces_.clear();
+        return false;
+    }
+}
+
+bool Model::load_file(const char *file)
 {
     if (!pos_.empty() || !faces_.empty()) return false;
     std::vector<char> text;

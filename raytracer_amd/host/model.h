@@ -94,6 +94,7 @@ public:
     uint32_t group_id() const { return group_id_; }
 
 private:
+    bool load_file(const char *file);  // load() without its guard against running out of memory
     bool from_cache_ = false;
     struct Face {
         uint32_t v[3];
