@@ -67,6 +67,9 @@ def parse():
     p.add_argument("--schedule", default="free", choices=["free", "reference"],
                    help="free: RT_FLAG_FREE_SCHEDULE (any processing order, same per-sample results); reference: every "
                         "step reproduces the reference's make_step state exactly")
+    p.add_argument("--arith", default="strict", choices=["strict", "mad"],
+                   help="strict: every product and sum rounded on its own; mad: multiply-adds fused at the stated places "
+                        "(RT_FLAG_ARITH_MAD; the reference builds its kernels with -cl-mad-enable, main.cpp:253)")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 disables it)")
     p.add_argument("--dragon", default=os.environ.get("RT_DRAGON_PLY", ""), help="path to dragon_vrip.ply if available")
     p.add_argument("--stage-timers", default="after", choices=["after", "timed"],
@@ -109,7 +112,7 @@ def cpu_baseline(args, files, seconds):
     first = (args.height - rows) // 2
     pool = args.width * rows
     sc = S.build_scene(files, args.width, args.height, pool, band_first=first, band_rows=rows)
-    o = O.Oracle(sc, warp_width=32, threads=threads)
+    o = O.Oracle(sc, warp_width=32, threads=threads, mad=args.arith == "mad")
     o.init_frame()
     t0 = time.time()
     warm = 0
@@ -158,7 +161,7 @@ def quick_rate(files, width, height, args, device, band=(0, 0), steps=32):
     pool = S.L.align_up(width * height, S.L.SORT_TILE)
     sc = S.build_scene(files, width, height, pool, band_first=band[0], band_rows=band[1], grid=args.grid)
     rt = api.RayTracer(sc, device=device, warp_width=args.warp_width, free_schedule=args.schedule == "free",
-                       shading=shading_flags(args))
+                       shading=shading_flags(args), mad=args.arith == "mad")
     rt.init_frame()
     _, steady = settle(rt, args.settle)
     rt.sync()
@@ -210,7 +213,7 @@ def main():
     sc = S.build_scene(files, args.width, args.height, pool, band_first=first, band_rows=rows,
                        tri_threshold=args.tri_threshold, aabb_threshold=args.aabb_threshold, grid=args.grid)
     rt = api.RayTracer(sc, device=device, warp_width=args.warp_width, free_schedule=args.schedule == "free",
-                       shading=shading_flags(args))
+                       shading=shading_flags(args), mad=args.arith == "mad")
     rt.init_frame()
 
     band = frame = None
@@ -338,7 +341,7 @@ def main():
                                    + ("primary + shadow rays" if args.shading == "reference" else
                                       f"primary rays, {args.bounces} {args.shading} bounces, shadow rays"),
                        "tiling": f"{world} row band(s), RGBA8 all-gather per frame" if world > 1 else "single GPU",
-                       "warp_width": args.warp_width, "schedule": args.schedule, "groups": sc.group_count,
+                       "warp_width": args.warp_width, "schedule": args.schedule, "arithmetic": args.arith, "groups": sc.group_count,
                        "tri_threshold": args.tri_threshold, "aabb_threshold": args.aabb_threshold},
             "mrays_primary_only": float(total[1]) / elapsed / 1e6,
             "stage_ms_per_step": per_launch, "stage_timers": args.stage_timers, "schedule": "serial" if args.serial else "leaf kernel on a second stream", "frame_resolve_gather_ms": gather_ms,

@@ -15,6 +15,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "csrc", "librt_hip.so")
 
 STAGE_NAMES = ("traverse", "shade", "sort", "compact", "leaves")
 FLAG_FREE_SCHEDULE = 1  # RT_FLAG_FREE_SCHEDULE
+FLAG_ARITH_MAD = 2      # RT_FLAG_ARITH_MAD
 SHADE_REFERENCE, SHADE_MIRROR, SHADE_DIFFUSE = 0, 1, 2
 
 
@@ -92,12 +93,12 @@ class RayTracer:
     """One GPU context.  Mirrors the reference's RayTracer: init (constructor + upload), init_frame,
     make_step, draw_frame, current_ray (main.cpp:185-206)."""
 
-    def __init__(self, scene, device=0, warp_width=0, sample_limit=0, hit_capacity=0, free_schedule=False, shading=0):
+    def __init__(self, scene, device=0, warp_width=0, sample_limit=0, hit_capacity=0, free_schedule=False, shading=0, mad=False):
         self.lib = hip_lib()
         self.scene = scene
         self.h = C.c_void_p()
         cfg = Config(device, scene.width, scene.height, scene.pool_size, warp_width, sample_limit, hit_capacity,
-                     scene.row_offset, (FLAG_FREE_SCHEDULE if free_schedule else 0) | shading)
+                     scene.row_offset, (FLAG_FREE_SCHEDULE if free_schedule else 0) | (FLAG_ARITH_MAD if mad else 0) | shading)
         rc = self.lib.rt_create(C.byref(cfg), C.byref(self.h))
         if rc:
             detail = self.lib.rt_last_error(self.h).decode() if self.h else ""

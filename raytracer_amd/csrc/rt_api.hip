@@ -41,10 +41,11 @@ struct rt_ctx {
     bool use_graph = true;
     bool free_schedule = false;  // RT_FLAG_FREE_SCHEDULE
     bool long_lists = false;     // the uploaded scene has a box list of more than kMaxClusteredBoxes boxes
+    bool mad = false;            // RT_FLAG_ARITH_MAD
 
     rt_group *grp = nullptr;
     rt_matrix *mat = nullptr;
-    rt_aabb *aabb = nullptr;
+    DevBox *aabb = nullptr;
     ClusterRecord *cluster = nullptr;
     rt_vertex *vtx = nullptr;
     uint32_t *tri = nullptr;
@@ -115,6 +116,7 @@ LaunchCtx launch_ctx(const rt_ctx *c)
     l.group_count = c->group_count;
     l.free_schedule = c->free_schedule;
     l.long_lists = c->long_lists;
+    l.mad = c->mad;
     return l;
 }
 
@@ -166,7 +168,8 @@ void free_scene(rt_ctx *c)
 
 // Expands one leaf's packed triangles into TriRecords with the float operations mesh_shader performs
 // per triangle (shader.cl:126-127), so the kernel's results do not depend on where they are done.
-void expand_leaf(const rt_mesh_shader &mesh, const rt_vertex *vtx, const uint32_t *tri, TriRecord *out)
+// (`mad`: the cross product's components as fused multiply-adds, as Arith<true>::cross has them.)
+void expand_leaf(const rt_mesh_shader &mesh, const rt_vertex *vtx, const uint32_t *tri, TriRecord *out, bool mad)
 {
     for (uint32_t i = 0; i < mesh.tri_count; i++) {
         const uint32_t word = tri[mesh.tri_offs + i];
@@ -179,9 +182,15 @@ void expand_leaf(const rt_mesh_shader &mesh, const rt_vertex *vtx, const uint32_
             r.p[k] = b[k] - a[k];
             r.q[k] = c[k] - a[k];
         }
-        r.n[0] = r.p[1] * r.q[2] - r.p[2] * r.q[1];
-        r.n[1] = r.p[2] * r.q[0] - r.p[0] * r.q[2];
-        r.n[2] = r.p[0] * r.q[1] - r.p[1] * r.q[0];
+        if (mad) {
+            r.n[0] = std::fmaf(r.p[1], r.q[2], -(r.p[2] * r.q[1]));
+            r.n[1] = std::fmaf(r.p[2], r.q[0], -(r.p[0] * r.q[2]));
+            r.n[2] = std::fmaf(r.p[0], r.q[1], -(r.p[1] * r.q[0]));
+        } else {
+            r.n[0] = r.p[1] * r.q[2] - r.p[2] * r.q[1];
+            r.n[1] = r.p[2] * r.q[0] - r.p[0] * r.q[2];
+            r.n[2] = r.p[0] * r.q[1] - r.p[1] * r.q[0];
+        }
     }
 }
 
@@ -210,17 +219,18 @@ ClusterRecord cluster_bounds(const rt_aabb *boxes, const std::vector<uint32_t> &
         }
         any = true;
     }
+    static const int lo_at[3] = {0, 1, 4}, hi_at[3] = {2, 3, 5};  // the layout of a DevBox
     for (int k = 0; k < 3; k++) {
-        r.f[k] = any ? std::nextafterf(lo[k], -INFINITY) : lo[k];
-        r.f[4 + k] = any ? std::nextafterf(hi[k], INFINITY) : hi[k];
+        r.f[lo_at[k]] = any ? std::nextafterf(lo[k], -INFINITY) : lo[k];
+        r.f[hi_at[k]] = any ? std::nextafterf(hi[k], INFINITY) : hi[k];
     }
-    r.f[3] = r.f[7] = 0;
+    r.f[6] = r.f[7] = 0;
     return r;
 }
 
 double surface(const ClusterRecord &r)
 {
-    const double x = double(r.f[4]) - r.f[0], y = double(r.f[5]) - r.f[1], z = double(r.f[6]) - r.f[2];
+    const double x = double(r.f[2]) - r.f[0], y = double(r.f[3]) - r.f[1], z = double(r.f[5]) - r.f[4];
     return x * y + y * z + z * x;
 }
 
@@ -405,7 +415,8 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
 {
     if (!cfg || !out) return RT_ERR_INVALID_VALUE;
     *out = nullptr;
-    if (!cfg->width || !cfg->height || !cfg->ray_count || (cfg->flags & ~(RT_FLAG_FREE_SCHEDULE | RT_FLAG_SHADING_MASK))) return RT_ERR_INVALID_VALUE;
+    if (!cfg->width || !cfg->height || !cfg->ray_count || (cfg->flags & ~(RT_FLAG_FREE_SCHEDULE | RT_FLAG_ARITH_MAD | RT_FLAG_SHADING_MASK)))
+        return RT_ERR_INVALID_VALUE;
     if (((cfg->flags >> 8) & 15u) > RT_SHADE_DIFFUSE) return RT_ERR_INVALID_VALUE;
     if (uint64_t(cfg->width) * cfg->height > 0x7FFFFFFFull) return RT_ERR_INVALID_VALUE;
     if (uint64_t(cfg->ray_count) + RT_SORT_TILE > 0x7FFFFFFFull) return RT_ERR_INVALID_VALUE;
@@ -416,6 +427,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
     rt_ctx *c = new rt_ctx;
     c->cfg = *cfg;
     c->free_schedule = (cfg->flags & RT_FLAG_FREE_SCHEDULE) != 0;
+    c->mad = (cfg->flags & RT_FLAG_ARITH_MAD) != 0;
     if (!c->cfg.warp_width) c->cfg.warp_width = 64;
     c->pool = (cfg->ray_count + RT_SORT_TILE - 1) / RT_SORT_TILE * RT_SORT_TILE;
     c->area_size = cfg->width * cfg->height;
@@ -530,15 +542,13 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     // spare entries.  The scan loops then need no tail handling and may read ahead past a list's end.
     // The device group table carries the re-laid-out offsets.
     std::vector<rt_group> dev_grp(grp, grp + n_groups);
-    std::vector<rt_aabb> dev_boxes;
+    std::vector<DevBox> dev_boxes;
     std::vector<ClusterRecord> dev_clusters;
     ClusterRecord no_cluster;
-    for (int k = 0; k < 8; k++) no_cluster.f[k] = k % 4 == 3 ? 0.0f : 1e30f;
+    for (int k = 0; k < 8; k++) no_cluster.f[k] = k >= 6 ? 0.0f : 1e30f;
     std::vector<uint32_t> dev_tri;
     std::vector<TriRecord> dev_rec;
-    rt_aabb never;
-    for (int k = 0; k < 3; k++) never.min[k] = never.max[k] = 1e30f;  // zero-size: exit parameter never exceeds entry
-    never.group_id = never.local_id = 0;
+    const DevBox never = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 0u, 0u};  // zero-size: exit parameter never exceeds entry
     TriRecord null_tri;
     std::memset(&null_tri, 0, sizeof(null_tri));  // zero normal: t is NaN, every comparison fails
     while (!work.empty()) {
@@ -559,7 +569,10 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
             }
             uint32_t *entry = reinterpret_cast<uint32_t *>(&dev_grp[id & RT_GROUP_ID_MASK]);
             entry[0] = uint32_t(dev_boxes.size());
-            dev_boxes.insert(dev_boxes.end(), aabb + s.aabb_offs, aabb + s.aabb_offs + s.aabb_count);
+            for (uint32_t i = 0; i < s.aabb_count; i++) {
+                const rt_aabb &b = aabb[s.aabb_offs + i];
+                dev_boxes.push_back(DevBox{b.min[0], b.min[1], b.max[0], b.max[1], b.min[2], b.max[2], b.group_id, b.local_id});
+            }
             while (dev_boxes.size() % 8) dev_boxes.push_back(never);
             // clusters of the list: [bounds, filled up to a multiple of four][membership masks, if any]
             // (a list of more than kMaxClusteredBoxes boxes gets one cluster per eight consecutive boxes; the kernel works out
@@ -594,7 +607,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
             dev_grp[id & RT_GROUP_ID_MASK].mesh.tri_offs = uint32_t(at);
             dev_tri.insert(dev_tri.end(), tri + s.tri_offs, tri + s.tri_offs + s.tri_count);
             dev_rec.resize(at + s.tri_count);
-            expand_leaf(s, vtx, tri, dev_rec.data() + at);
+            expand_leaf(s, vtx, tri, dev_rec.data() + at, c->mad);
             if (dev_tri.size() % 2) {
                 dev_tri.push_back(0);
                 dev_rec.push_back(null_tri);
@@ -636,7 +649,7 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     RT_HIP(c, hipMemset(c->grp_data, 0, sizeof(rt_group_data) * size_t(G)));
     RT_HIP(c, hipMemcpy(c->grp, dev_grp.data(), sizeof(rt_group) * n_groups, hipMemcpyHostToDevice));
     if (n_mat) RT_HIP(c, hipMemcpy(c->mat, mat, sizeof(rt_matrix) * n_mat, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(c->aabb, dev_boxes.data(), sizeof(rt_aabb) * dev_boxes.size(), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->aabb, dev_boxes.data(), sizeof(DevBox) * dev_boxes.size(), hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->cluster, dev_clusters.data(), sizeof(ClusterRecord) * dev_clusters.size(), hipMemcpyHostToDevice));
     if (n_vtx) RT_HIP(c, hipMemcpy(c->vtx, vtx, sizeof(rt_vertex) * n_vtx, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->tri, dev_tri.data(), sizeof(uint32_t) * dev_tri.size(), hipMemcpyHostToDevice));

@@ -4,6 +4,8 @@
 // -ffp-contract=off, every expression below is evaluated in float exactly as written, division and
 // sqrt are the correctly rounded ones.  dot(a,b) = (ax*bx + ay*by) + az*bz,
 // normalize(v) = v * (1 / sqrt(dot(v,v))), pow(x,5) and pow(x,100) are products of repeated squares.
+// Kernels instantiated with MAD (contexts created with RT_FLAG_ARITH_MAD) fuse the multiply-adds that
+// struct Arith<true> names, and only those; see include/rt_hip.h.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -84,7 +86,7 @@ struct CompactWorkspace {
 };
 
 // One 32-byte record of the culling data of a box list: the bounds of a cluster of boxes
-// (min.xyz, -, max.xyz, -) or the 256-bit membership mask of a cluster.
+// (laid out like a DevBox) or the 256-bit membership mask of a cluster.
 union alignas(32) ClusterRecord {
     float f[8];
     uint32_t u[8];
@@ -96,10 +98,18 @@ constexpr uint32_t kClusterCountShift = 8, kClusterCountMask = 0xFF, kClusterMas
 // eight consecutive boxes and is scanned part by part.
 constexpr uint32_t kMaxClusteredBoxes = 256, kMaxListBoxes = 65536;
 
+// Device copy of a box (rt_aabb re-ordered): the x and y of either corner and the two z share aligned register
+// pairs, so that the slab test's three subtract-multiply (or fused multiply-add) steps each do two values at once.
+struct alignas(32) DevBox {
+    float lo_x, lo_y, hi_x, hi_y, lo_z, hi_z;
+    uint32_t group_id, local_id;
+};
+static_assert(sizeof(DevBox) == 32, "a box is one 32-byte record");
+
 struct Scene {
     const rt_group *grp;
     const rt_matrix *mat;
-    const rt_aabb *aabb;
+    const DevBox *aabb;
     const ClusterRecord *cluster;
     const rt_vertex *vtx;
     const uint32_t *tri;
@@ -205,6 +215,50 @@ __device__ __forceinline__ void store_commit(RaySlot *ray, uint32_t material_id,
 }
 
 __device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+
+// The arithmetic of the two modes (rt_config.flags, RT_FLAG_ARITH_MAD).  Arith<false>: every product and sum is
+// rounded on its own.  Arith<true>: a product that feeds a sum is fused with it at exactly these places.
+template <bool MAD>
+struct Arith {
+    static __device__ __forceinline__ float dot(V3 a, V3 b)
+    {
+        if (MAD) return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+        return a.x * b.x + a.y * b.y + a.z * b.z;
+    }
+    static __device__ __forceinline__ V3 cross(V3 a, V3 b)
+    {
+        if (MAD)
+            return V3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
+        return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    }
+    // a * s + b
+    static __device__ __forceinline__ V3 madd(V3 a, float s, V3 b)
+    {
+        if (MAD) return V3{__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z)};
+        return V3{a.x * s + b.x, a.y * s + b.y, a.z * s + b.z};
+    }
+    // (a * s + b * t) + c * u
+    static __device__ __forceinline__ V3 lin3(V3 a, float s, V3 b, float t, V3 c, float u)
+    {
+        if (MAD)
+            return V3{__builtin_fmaf(c.x, u, __builtin_fmaf(b.x, t, a.x * s)), __builtin_fmaf(c.y, u, __builtin_fmaf(b.y, t, a.y * s)),
+                      __builtin_fmaf(c.z, u, __builtin_fmaf(b.z, t, a.z * s))};
+        return (a * s + b * t) + c * u;
+    }
+    static __device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+    // the same for two values per operand (packed FP32)
+    static __device__ __forceinline__ f32x2 dot2(f32x2 ax, f32x2 ay, f32x2 az, f32x2 bx, f32x2 by, f32x2 bz)
+    {
+        if (MAD) return __builtin_elementwise_fma(az, bz, __builtin_elementwise_fma(ay, by, ax * bx));
+        return (ax * bx + ay * by) + az * bz;
+    }
+    // p * q - r * s
+    static __device__ __forceinline__ f32x2 cross2(f32x2 p, f32x2 q, f32x2 r, f32x2 s)
+    {
+        if (MAD) return __builtin_elementwise_fma(p, q, -(r * s));
+        return p * q - r * s;
+    }
+};
 
 __device__ __forceinline__ float pow5(float x)
 {

@@ -96,6 +96,7 @@ __device__ __forceinline__ uint32_t reset_ray(RaySlot *ray, HotRay h, uint32_t g
 
 // The hot fields of sample number `sample` as init_ray and reset_ray set them (ray-tracer.cl:10-16, 56-74):
 // a camera ray through the sample's sub-pixel position, about to enter the camera's root group.
+template <bool MAD>
 __device__ __forceinline__ HotRay camera_ray(const rt_camera &cam, const DevGlobal *glob, uint32_t sample)
 {
     const uint32_t total = cam.width * cam.height;
@@ -115,7 +116,7 @@ __device__ __forceinline__ HotRay camera_ray(const rt_camera &cam, const DevGlob
     h.t_min = 0.001f;
     h.t_max = INFINITY;
     h.start = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
-    h.dir = normalize((tl + dx * x) + dy * y);
+    h.dir = Arith<MAD>::normalize(Arith<MAD>::madd(dy, y, Arith<MAD>::madd(dx, x, tl)));
     return h;
 }
 
@@ -140,7 +141,7 @@ __device__ __forceinline__ uint32_t blocked_sample(const rt_camera &cam, uint32_
 // LEAN: `root` is not stored again -- every slot of the pool got the camera's root when the frame was
 // initialised, and nothing else ever writes it -- and neither is the weight: a camera ray that has not
 // bounced has weight one, which is what ray_weight() gives for it without looking at the slot.
-template <bool LEAN>
+template <bool LEAN, bool MAD>
 __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlobal *glob, RaySlot *ray,
                                              rt_hit_record *hits, uint32_t group_count, uint32_t sample, bool &started)
 {
@@ -150,7 +151,7 @@ __device__ __forceinline__ uint32_t init_ray(const rt_camera &cam, const DevGlob
     if (!LEAN) ray->weight = make_float4(1, 1, 1, 1);
     if (!LEAN) ray->root = RayHit{0.0f, cam.root_group, cam.root_local, 0u};
     if (sample < step_constant(&glob->hit_capacity)) hits[sample] = rt_hit_record{INFINITY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    return reset_ray<LEAN>(ray, camera_ray(cam, glob, sample), cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
+    return reset_ray<LEAN>(ray, camera_ray<MAD>(cam, glob, sample), cam.root_group, cam.root_local, 0u, RT_SKY_GROUP);
 }
 
 // One atomic per wave for a per-lane event count (each counted lane adds `weight`, wave-uniform), to
@@ -174,12 +175,13 @@ __global__ void k_init_groups(rt_group_data *grp_data, uint32_t group_count)
 }
 
 // init_rays (ray-tracer.cl:76-82)
+template <bool MAD>
 __global__ void k_init_rays(ProcessArgs a, uint32_t pool)
 {
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= pool) return;
     bool started;
-    const uint32_t key = init_ray<false>(a.cam, a.frame.glob, &a.frame.rays[index], a.frame.hits, a.group_count, index, started);
+    const uint32_t key = init_ray<false, MAD>(a.cam, a.frame.glob, &a.frame.rays[index], a.frame.hits, a.group_count, index, started);
     a.frame.index[index] = rt_index_pair{key, index};
     count_lanes(a.frame, kPrimarySpawned, started);
     if (index) return;
@@ -198,7 +200,7 @@ __global__ void k_load_rays(ProcessArgs a, uint32_t pool, const rt_ray *rays, ui
     if (index < n_rays) {
         bool started;
         RaySlot *ray = &a.frame.rays[index];
-        key = init_ray<false>(a.cam, a.frame.glob, ray, a.frame.hits, a.group_count, index, started);
+        key = init_ray<false, false>(a.cam, a.frame.glob, ray, a.frame.hits, a.group_count, index, started);
         const rt_ray r = rays[index];
         asm volatile("" ::: "memory");  // the caller's ray goes over what init_ray has stored
         ray->t_min = r.start_min[3];
@@ -244,6 +246,7 @@ struct LocalRay {
     V3 m0, m1, m2;  // columns of the instance rotation (identity for world-space groups)
 };
 
+template <bool MAD>
 __device__ __forceinline__ LocalRay make_local(uint32_t g, const HotRay &h, uint32_t local0, const rt_matrix *mat_list)
 {
     LocalRay r;
@@ -262,9 +265,9 @@ __device__ __forceinline__ LocalRay make_local(uint32_t g, const HotRay &h, uint
         r.m2 = v3(mx.z, my.z, mz.z);
         const V3 rel = r.start - v3(mx.w, my.w, mz.w);
         const V3 vx = xyz(mx), vy = xyz(my), vz = xyz(mz);
-        r.start = (vx * rel.x + vy * rel.y) + vz * rel.z;
+        r.start = Arith<MAD>::lin3(vx, rel.x, vy, rel.y, vz, rel.z);
         const V3 d = r.dir;
-        r.dir = (vx * d.x + vy * d.y) + vz * d.z;
+        r.dir = Arith<MAD>::lin3(vx, d.x, vy, d.y, vz, d.z);
     }
     return r;
 }
@@ -355,15 +358,16 @@ __device__ __forceinline__ bool finish_in_sky_or_light(const ProcessArgs &a, con
 // A sample that bounces instead of being shaded (RT_SHADE_MIRROR: shader.cl:37-39; RT_SHADE_DIFFUSE: a
 // cosine-weighted direction, the normal plus a uniform point of the unit sphere, drawn by Marsaglia's
 // rejection method from hashed counters so that it only depends on seed, sample and bounce number).
-template <bool LEAN>
+template <bool LEAN, bool MAD>
 __device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, HotRay h, float4 color, uint32_t shading, uint32_t depth)
 {
-    const V3 dir = h.dir, norm = normalize(xyz(ray->norm));
+    typedef Arith<MAD> A;
+    const V3 dir = h.dir, norm = A::normalize(xyz(ray->norm));
     V3 out;
     if ((shading & 15u) == RT_SHADE_MIRROR) {
-        out = dir - norm * (2 * dot(dir, norm));
+        out = A::madd(norm, -(2 * A::dot(dir, norm)), dir);  // dir - norm * (2 dot(dir, norm))
     } else {
-        const V3 up = dot(dir, norm) > 0 ? v3(-norm.x, -norm.y, -norm.z) : norm;
+        const V3 up = A::dot(dir, norm) > 0 ? v3(-norm.x, -norm.y, -norm.z) : norm;
         const uint32_t base = hash32((shading >> 8) ^ h.sample_id * 0x9E3779B9u ^ depth * 0x85EBCA6Bu);
         float x1 = 0, x2 = 0, s = 0;
         for (uint32_t k = 0; k < 8; k++) {
@@ -376,7 +380,7 @@ __device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, HotRay h, float4
         }
         const float r = 2 * sqrtf(1 - s);
         const V3 v = up + v3(x1 * r, x2 * r, 1 - 2 * s);
-        const float len2 = dot(v, v);
+        const float len2 = A::dot(v, v);
         out = len2 > 1e-12f ? v * (1.0f / sqrtf(len2)) : up;
         float4 w = ray_weight(ray, h.type);
         w.x *= color.x;
@@ -386,25 +390,26 @@ __device__ __forceinline__ uint32_t bounce_shader(RaySlot *ray, HotRay h, float4
     }
     if ((shading & 15u) == RT_SHADE_MIRROR && h.type == RT_RAY_PRIMARY) ray->weight = make_float4(1, 1, 1, 1);  // no longer implied
     h.type = RT_RAY_PRIMARY | (depth + 1) << 8;
-    h.start = h.start + dir * h.t_max;
+    h.start = A::madd(dir, h.t_max, h.start);
     h.dir = out;
     const RayHit root = ray->root;
     return reset_ray<LEAN>(ray, h, root.group_id, root.local0, root.local1, RT_SKY_GROUP);
 }
 
 // mat_shader's direct-light part (shader.cl:20-40) for a ray whose hot fields and stored normal are at hand.
-template <bool LEAN>
+template <bool LEAN, bool MAD>
 __device__ __forceinline__ uint32_t direct_light_shader(RaySlot *ray, HotRay h, V3 stored_norm, float4 color)
 {
+    typedef Arith<MAD> A;
     const RayHit root = ray->root;  // (asked for before anything is stored)
     const float l = 0.57735026f;
     const V3 light = v3(l, -l, l);
     const float alpha = 100, f0 = 0.04f;
-    const V3 dir = h.dir, norm = normalize(stored_norm);
-    const V3 hvec = normalize(light - dir);
-    float spec = (alpha + 2) / 8 * pow100(fmaxf(0.0f, dot(norm, hvec)));
-    spec *= f0 + (1 - f0) * pow5(fmaxf(0.0f, -dot(dir, hvec)));
-    const float lambert = fmaxf(0.0f, dot(light, norm));
+    const V3 dir = h.dir, norm = A::normalize(stored_norm);
+    const V3 hvec = A::normalize(light - dir);
+    float spec = (alpha + 2) / 8 * pow100(fmaxf(0.0f, A::dot(norm, hvec)));
+    spec *= f0 + (1 - f0) * pow5(fmaxf(0.0f, -A::dot(dir, hvec)));
+    const float lambert = fmaxf(0.0f, A::dot(light, norm));
     const float sw = spec * color.w;
     const V3 c = v3(color.x + sw, color.y + sw, color.z + sw) * lambert;
 
@@ -415,26 +420,27 @@ __device__ __forceinline__ uint32_t direct_light_shader(RaySlot *ray, HotRay h, 
     w.w *= 1.0f;
     ray->weight = w;
     h.type = RT_RAY_SHADOW;
-    h.start = h.start + dir * h.t_max;
+    h.start = A::madd(dir, h.t_max, h.start);
     h.dir = light;
     return reset_ray<LEAN>(ray, h, root.group_id, root.local0, root.local1, RT_LIGHT_GROUP);
 }
 
-template <bool LEAN>
+template <bool LEAN, bool MAD>
 __device__ __forceinline__ uint32_t mat_shader(RaySlot *ray, float4 color, uint32_t shading)
 {
     HotRay h = load_hot(ray);
     if (shading & 15u) {
         const uint32_t depth = h.type >> 8;
-        if (depth < ((shading >> 4) & 15u)) return bounce_shader<LEAN>(ray, h, color, shading, depth);
+        if (depth < ((shading >> 4) & 15u)) return bounce_shader<LEAN, MAD>(ray, h, color, shading, depth);
     }
-    return direct_light_shader<LEAN>(ray, h, xyz(ray->norm), color);
+    return direct_light_shader<LEAN, MAD>(ray, h, xyz(ray->norm), color);
 }
 
 // Free schedule: a ray whose queue has emptied goes to its end group (sky, light, material or spawn).  The
 // reference spends a step of its own on that group's shader; here the visiting kernel runs it on the
 // spot.  Spawn and the dead-ray bin (shader bits 0) stay keys: a finished slot is re-initialised by the
 // box kernel at the next step, when its position in the sorted index gives it its sample id.
+template <bool MAD>
 __device__ __forceinline__ uint32_t run_end_group(uint32_t key, RaySlot *ray, const ProcessArgs &a)
 {
     const uint32_t shader = (key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK;
@@ -444,7 +450,7 @@ __device__ __forceinline__ uint32_t run_end_group(uint32_t key, RaySlot *ray, co
     if (shader != RT_SH_MATERIAL) return sky_or_light_shader<true>(a, ray, shader == RT_SH_LIGHT);
     const float4 color = *reinterpret_cast<const float4 *>(a.scene.grp + (key & kIdMask));
     count_lanes(a.frame, kShadowSpawned, true);
-    return mat_shader<true>(ray, color, step_constant(&a.frame.glob->shading));
+    return mat_shader<true, MAD>(ray, color, step_constant(&a.frame.glob->shading));
 }
 
 // Asks for the 64-byte lines of a wave-uniform list ahead of the scan that reads it through the scalar path one
@@ -483,16 +489,17 @@ __device__ __forceinline__ void touch_done(uint32_t sum) { asm volatile("" ::"v"
 
 // LEAN (free schedule): `orig` is not kept up, and a ray whose queue has emptied is not given its end group
 // as head -- the caller runs that group's shader right away.
-template <bool LEAN>
+template <bool LEAN, bool MAD>
 __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const ProcessArgs &a)
 {
+    typedef Arith<MAD> A;
     MISC_STAMP(t_start);
     const u32x4 grp = *const_ptr<u32x4>(a.scene.grp + (g & kIdMask));  // vtx_offs, tri_offs, tri_count, material_id
     // What the scan needs from the slot (its first 64 bytes: ray and head of the queue) is requested at once.
     const HotRay h = load_hot(ray);
     const uint32_t queue_len = h.queue_len;
     const RayHit head = ray->queue[0];
-    const LocalRay lr = make_local(g, h, head.local0, a.scene.mat);
+    const LocalRay lr = make_local<MAD>(g, h, head.local0, a.scene.mat);
     // (asked for before the instance matrix the leaf kernel is 1 % faster alone, but the four registers the requests
     // hold across the transformation cost 12 bytes of scratch and the step comes out slower)
     const uint32_t touched = touch_sum(touch_list(a.scene.tri_rec + grp.y, (grp.z + 1) / 2 * (2 * (uint32_t)sizeof(TriRecord))));
@@ -520,14 +527,14 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
         const f32x2 r0x = {x.s0, x.s1}, r0y = {x.s2, x.s3}, r0z = {x.s4, x.s5};
         const f32x2 nx = {z.s2, z.s3}, ny = {z.s4, z.s5}, nz = {z.s6, z.s7};
         const f32x2 rx = r0x - sx, ry = r0y - sy, rz = r0z - sz;
-        const f32x2 w = reciprocal2((dx * nx + dy * ny) + dz * nz);
-        const f32x2 tt = ((rx * nx + ry * ny) + rz * nz) * w;
+        const f32x2 w = reciprocal2(A::dot2(dx, dy, dz, nx, ny, nz));
+        const f32x2 tt = A::dot2(rx, ry, rz, nx, ny, nz) * w;
         const bool near0 = tt.x > lr.tmin && tt.x < best, near1 = tt.y > lr.tmin && tt.y < best;
         if (!(near0 || near1)) return;
         const f32x2 px = {x.s6, x.s7}, py = {y.s0, y.s1}, pz = {y.s2, y.s3};
         const f32x2 qx = {y.s4, y.s5}, qy = {y.s6, y.s7}, qz = {z.s0, z.s1};
-        const f32x2 cx = dy * rz - dz * ry, cy = dz * rx - dx * rz, cz = dx * ry - dy * rx;  // cross(dir, r)
-        const f32x2 u = -((qx * cx + qy * cy) + qz * cz) * w, v = ((px * cx + py * cy) + pz * cz) * w;
+        const f32x2 cx = A::cross2(dy, rz, dz, ry), cy = A::cross2(dz, rx, dx, rz), cz = A::cross2(dx, ry, dy, rx);  // cross(dir, r)
+        const f32x2 u = -A::dot2(qx, qy, qz, cx, cy, cz) * w, v = A::dot2(px, py, pz, cx, cy, cz) * w;
         const f32x2 uv = u + v;
         if (near0 && u.x >= 0 && v.x >= 0 && uv.x <= 1) {
             best = tt.x;
@@ -581,8 +588,8 @@ __device__ __forceinline__ uint32_t visit_mesh(uint32_t g, RaySlot *ray, const P
             const float4 n0 = *reinterpret_cast<const float4 *>(vtx[word & 0x3FF].norm);
             const float4 n1 = *reinterpret_cast<const float4 *>(vtx[(word >> 10) & 0x3FF].norm);
             const float4 n2 = *reinterpret_cast<const float4 *>(vtx[(word >> 20) & 0x3FF].norm);
-            const V3 nn = (xyz(n0) * (1 - hit_u - hit_v) + xyz(n1) * hit_u) + xyz(n2) * hit_v;
-            nw = (lr.m0 * nn.x + lr.m1 * nn.y) + lr.m2 * nn.z;
+            const V3 nn = A::lin3(xyz(n0), 1 - hit_u - hit_v, xyz(n1), hit_u, xyz(n2), hit_v);
+            nw = A::lin3(lr.m0, nn.x, lr.m1, nn.y, lr.m2, nn.z);
             end_group = grp.w;
         }
     }
@@ -705,26 +712,66 @@ constexpr int kMeshThreads = RT_MESH_THREADS;
 #endif
 constexpr int kAabbCap = RT_AABB_CAP;
 
-// One box against one ray: entry and exit parameter of the slab test (shader.cl:86-91).
-__device__ __forceinline__ bool box_test(const f32x8 b, const V3 start, const V3 inv_dir, float ray_min, float ray_max,
-                                         float &t_entry)
+// What the slab test needs of a ray (shader.cl:79-91): the reciprocal direction, and the start -- or, when the
+// multiply-adds are fused, -(start * reciprocal direction), which turns (corner - start) * inv_dir into one fused
+// operation per corner coordinate.  x and y of each share a register pair; the two z values share a third
+// (the packed operation on the corners' z reads one half of it for both corners).
+template <bool MAD>
+struct Slab {
+    f32x2 a_xy, i_xy, z;  // z = {1 / dir.z, start.z or -(start.z / dir.z)}
+    float ray_min, ray_max;
+};
+template <bool MAD>
+__device__ __forceinline__ Slab<MAD> make_slab(const V3 start, const V3 dir, float ray_min, float ray_max)
 {
-#ifndef RT_PLAIN_BOX_TEST
-    // x and y of either corner go through the packed subtract and multiply (two lanes' worth per instruction)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 s_xy = {start.x, start.y}, i_xy = {inv_dir.x, inv_dir.y};
-    const f32x2 lo_xy = {b.s0, b.s1}, hi_xy = {b.s4, b.s5};
-    const f32x2 p1 = (lo_xy - s_xy) * i_xy, p2 = (hi_xy - s_xy) * i_xy;
-    const V3 pos1 = v3(p1.x, p1.y, (b.s2 - start.z) * inv_dir.z);
-    const V3 pos2 = v3(p2.x, p2.y, (b.s6 - start.z) * inv_dir.z);
-#else
-    const V3 pos1 = (v3(b.s0, b.s1, b.s2) - start) * inv_dir;
-    const V3 pos2 = (v3(b.s4, b.s5, b.s6) - start) * inv_dir;
-#endif
-    const float t_min = fmaxf(fmaxf(fminf(pos1.x, pos2.x), fminf(pos1.y, pos2.y)), fminf(pos1.z, pos2.z));
-    const float t_max = fminf(fminf(fmaxf(pos1.x, pos2.x), fmaxf(pos1.y, pos2.y)), fmaxf(pos1.z, pos2.z));
-    t_entry = fmaxf(t_min, ray_min);
-    return t_max > t_min && t_max > ray_min && t_min < ray_max;
+    const V3 inv = v3(1 / dir.x, 1 / dir.y, 1 / dir.z);
+    const V3 a = MAD ? v3(-(start.x * inv.x), -(start.y * inv.y), -(start.z * inv.z)) : start;
+    return Slab<MAD>{f32x2{a.x, a.y}, f32x2{inv.x, inv.y}, f32x2{inv.z, a.z}, ray_min, ray_max};
+}
+
+// One box (a DevBox: lo.xy, hi.xy, lo.z, hi.z, two ids) against one ray: entry and exit parameter of the slab test
+// (shader.cl:86-91), three packed operations for the six corner coordinates.  UNIFORM: the box is the same for
+// every lane and sits in scalar registers.  The reference accepts a box iff
+// t_max > t_min && t_max > ray.min && t_min < ray.max; with t_entry = max(t_min, ray.min) the first two are
+// t_max > t_entry for every ray whose ray.min is a number (max() then returns one of its operands, and a t_min
+// that is not a number fails the third comparison).
+template <bool MAD, bool UNIFORM = true>
+__device__ __forceinline__ bool box_test(const f32x8 b, const Slab<MAD> &r, float &t_entry)
+{
+    const f32x2 lo_xy = {b.s0, b.s1}, hi_xy = {b.s2, b.s3}, z = {b.s4, b.s5};
+    f32x2 p1, p2, pz;
+    // The z of both corners against {1 / dir.z, a.z}: both halves of the operation read the first half of that pair
+    // as factor and the second as the term (op_sel), where the compiler would hold each value twice.
+    if (MAD) {
+        p1 = __builtin_elementwise_fma(lo_xy, r.i_xy, r.a_xy);
+        p2 = __builtin_elementwise_fma(hi_xy, r.i_xy, r.a_xy);
+        if (UNIFORM) asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(pz) : "s"(z), "v"(r.z));
+        else asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(pz) : "v"(z), "v"(r.z));
+    } else {
+        p1 = (lo_xy - r.a_xy) * r.i_xy;
+        p2 = (hi_xy - r.a_xy) * r.i_xy;
+        // (z - start.z) * inv.z: the subtraction as an addition of the negated second half
+        if (UNIFORM)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %0, %0, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=&v"(pz) : "s"(z), "v"(r.z));
+        else
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %0, %0, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=&v"(pz) : "v"(z), "v"(r.z));
+    }
+    const float t_min = fmaxf(fmaxf(fminf(p1.x, p2.x), fminf(p1.y, p2.y)), fminf(pz.x, pz.y));
+    const float t_max = fminf(fminf(fmaxf(p1.x, p2.x), fmaxf(p1.y, p2.y)), fmaxf(pz.x, pz.y));
+    t_entry = fmaxf(t_min, r.ray_min);
+    return t_max > t_entry && t_min < r.ray_max;
+}
+
+// The two ids of box `bi` of a list, as two 4-byte loads: taken as one 8-byte load they would each need an aligned
+// register pair, and the box kernel, which has no register to spare, would spill eleven more values.
+__device__ __forceinline__ void box_ids(const DevBox *list, uint32_t bi, uint32_t &group_id, uint32_t &local_id)
+{
+    group_id = list[bi].group_id;
+    uint32_t again = bi;
+    asm("" : "+v"(again));  // (keeps the compiler from seeing that the two addresses are neighbours)
+    local_id = list[again].local_id;
 }
 
 __device__ __forceinline__ float lane_value(float v, uint32_t lane)
@@ -739,8 +786,8 @@ __device__ __forceinline__ float lane_value(float v, uint32_t lane)
 // lane per exchange: all exchanges of one inner loop of the network touch disjoint pairs.  c_pos/c_idx
 // are this wave's 64-entry scratch lists in LDS.  Returns the candidate count (0 when more than 64
 // boxes are accepted: the reference gives up on the whole node), the list is left sorted.
-__device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t count, const V3 start, const V3 inv_dir,
-                                                   float ray_min, float ray_max, float *c_pos, uint16_t *c_idx)
+template <bool MAD>
+__device__ __forceinline__ uint32_t wave_visit_one(const DevBox *list, uint32_t count, const Slab<MAD> &slab, float *c_pos, uint16_t *c_idx)
 {
     const unsigned long long active = __ballot(true);
     const unsigned long long below = (1ull << lane_id()) - 1;
@@ -751,11 +798,11 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
         bool hit = false;
         float t = 0;
         if (i < count) {
-            const float4 lo = *reinterpret_cast<const float4 *>(list[i].min), hi = *reinterpret_cast<const float4 *>(list[i].max);
+            const float4 lo = *reinterpret_cast<const float4 *>(&list[i].lo_x), hi = *reinterpret_cast<const float4 *>(&list[i].lo_z);
             f32x8 b;
             b.s0 = lo.x;  b.s1 = lo.y;  b.s2 = lo.z;  b.s3 = lo.w;
             b.s4 = hi.x;  b.s5 = hi.y;  b.s6 = hi.z;  b.s7 = hi.w;
-            hit = box_test(b, start, inv_dir, ray_min, ray_max, t);
+            hit = box_test<MAD, false>(b, slab, t);
         }
         const unsigned long long m = __ballot(hit);
         const uint32_t at = total + __popcll(m & below);
@@ -800,7 +847,7 @@ __device__ __forceinline__ uint32_t wave_visit_one(const rt_aabb *list, uint32_t
 // caller hands every lane that ray's group and slot): the scan and the candidate sort are done by
 // wave_visit_one in the wave's lists c_pos/c_idx with the reference's limit of 64 candidates, and
 // only the lane `owner` merges and stores.
-template <int CAP, int THREADS, bool COOP, bool LEAN, bool FRESH = false, typename PLACE = uint8_t>
+template <int CAP, int THREADS, bool COOP, bool LEAN, bool MAD, bool FRESH = false, typename PLACE = uint8_t>
 __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const ProcessArgs &a, float (*s_pos)[THREADS],
                                            PLACE (*s_idx)[THREADS], float *c_pos, uint16_t *c_idx, uint32_t owner,
                                            uint32_t tid, uint32_t &new_key, uint32_t &group_flags, uint32_t sample = 0,
@@ -815,7 +862,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     // now.  No load is issued once the stores of the merge begin.
     // FRESH: the visit that starts sample number `sample`.  Its slot has not been written: the ray is worked
     // out here, there are no pending entries, and the slot's hot fields are stored whole at the end.
-    HotRay h = FRESH ? camera_ray(a.cam, a.frame.glob, sample) : load_hot(ray);
+    HotRay h = FRESH ? camera_ray<MAD>(a.cam, a.frame.glob, sample) : load_hot(ray);
     const RayHit head = FRESH ? RayHit{0.001f, a.cam.root_group, a.cam.root_local, 0u} : ray->queue[0];
     const uint32_t old_len = FRESH ? 1u : h.queue_len;
     const float reach = h.t_max;
@@ -832,13 +879,13 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         store_hot(ray, h);
         ray->queue[0] = head;
     };
-    const LocalRay lr = make_local(g, h, head.local0, a.scene.mat);
-    const V3 inv_dir = v3(1 / lr.dir.x, 1 / lr.dir.y, 1 / lr.dir.z);
+    const LocalRay lr = make_local<MAD>(g, h, head.local0, a.scene.mat);
+    const Slab<MAD> slab = make_slab<MAD>(lr.start, lr.dir, lr.tmin, lr.tmax);
     if (!COOP) count_lanes(a.frame, kBoxTests, true, count);  // a redone visit was counted the first time
 
     uint32_t n = 0;
     if (COOP) {
-        n = wave_visit_one(a.scene.aabb + grp.x, count, lr.start, inv_dir, lr.tmin, lr.tmax, c_pos, c_idx);
+        n = wave_visit_one<MAD>(a.scene.aabb + grp.x, count, slab, c_pos, c_idx);
         if (lane_id() != owner) return true;
     } else {
     // Box scan.  The list is wave-uniform and comes through the scalar cache.  First the bounds of the
@@ -855,7 +902,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         if (FRESH) put_fresh_sample_in_its_slot();
         return false;
     }
-    asm volatile("" ::"v"(inv_dir.x), "v"(inv_dir.y), "v"(inv_dir.z), "v"(lr.start.x));
+    asm volatile("" ::"v"(slab.i_xy.x), "v"(slab.i_xy.y), "v"(slab.z.x), "v"(slab.a_xy.x));
     AABB_STAMP(t_loaded);
     bool spill = false;
     const bool long_list = (grp.z & kClusterLong) != 0;
@@ -864,7 +911,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 #endif
     auto test_box = [&](const f32x8 b, uint32_t i) {
         float t;
-        if (box_test(b, lr.start, inv_dir, lr.tmin, lr.tmax, t)) {
+        if (box_test<MAD>(b, slab, t)) {
             if (n < CAP) {
                 s_pos[n][tid] = t;
                 s_idx[n][tid] = (PLACE)i;
@@ -882,8 +929,8 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         ConstPtr<f32x16> two = const_ptr<f32x16>(a.scene.cluster + grp.w + seg / 8);  // bounds of two clusters per load
         auto test_two = [&](const f32x16 p, uint32_t c) {
             float t;
-            if (__ballot(box_test(p.lo, lr.start, inv_dir, lr.tmin, lr.tmax, t))) entered |= 1u << c;
-            if (__ballot(box_test(p.hi, lr.start, inv_dir, lr.tmin, lr.tmax, t))) entered |= 2u << c;
+            if (__ballot(box_test<MAD>(p.lo, slab, t))) entered |= 1u << c;
+            if (__ballot(box_test<MAD>(p.hi, slab, t))) entered |= 2u << c;
         };
         // four clusters per round trip (the bounds are filled up to a multiple of four with clusters no ray enters)
         f32x16 c0 = two[0], c1 = two[1];
@@ -1041,7 +1088,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
     // land inside the queue.  Their child ids are fetched together, then every surviving entry is
     // stored to its place from registers -- independent stores, no load in between.
     const bool take0 = (grp.z & RT_F_LOCAL0) != 0, take1 = (grp.z & RT_F_LOCAL1) != 0;
-    const rt_aabb *list = a.scene.aabb + grp.x;
+    const DevBox *list = a.scene.aabb + grp.x;
     float cand_pos[RT_MAX_QUEUE_LEN];
     uint32_t cand_group[RT_MAX_QUEUE_LEN], cand_local[RT_MAX_QUEUE_LEN];
 #pragma unroll
@@ -1052,8 +1099,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
             const uint32_t bi = COOP ? c_idx[j] : s_idx[j][tid];
             cand_pos[j] = COOP ? c_pos[j] : s_pos[j][tid];
             if (j < 4) {  // (the later candidates' ids are fetched below, and only by waves that have such candidates)
-                cand_group[j] = list[bi].group_id;
-                cand_local[j] = list[bi].local_id;
+                box_ids(list, bi, cand_group[j], cand_local[j]);
             }
         }
     }
@@ -1142,8 +1188,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
         for (int j = 4; j < RT_MAX_QUEUE_LEN; j++) {
             if ((uint32_t)j < n) {
                 const uint32_t bi = COOP ? c_idx[j] : s_idx[j][tid];
-                cand_group[j] = list[bi].group_id;
-                cand_local[j] = list[bi].local_id;
+                box_ids(list, bi, cand_group[j], cand_local[j]);
             }
         }
     }
@@ -1236,7 +1281,7 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 // (run_end_group) and carries the parked entries over, so no shading launch is needed.
 // PLACE: one byte per candidate's place in its list, or two for scenes with lists of more than 256 boxes
 // (24 instead of 20 KB of LDS per workgroup for the columns, i.e. six instead of seven workgroups per CU).
-template <bool FREE, typename PLACE>
+template <bool FREE, bool MAD, typename PLACE>
 __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spill_list, float (*s_pos)[kAabbThreads],
                                              PLACE (*s_idx)[kAabbThreads], uint32_t head_lds)
 {
@@ -1277,8 +1322,8 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
         if (shader != RT_SH_AABB) {
             // a sample beyond the limit (dead-ray bin), a scene whose root is a leaf, or a shader key left by
             // rt_init_frame/rt_trace_closest: no box visit
-            if (fresh) reset_ray<true>(ray, camera_ray(a.cam, glob, sample), a.cam.root_group, a.cam.root_local, 0u, RT_SKY_GROUP);
-            a.frame.next[index] = rt_index_pair{run_end_group(key, ray, a), entry.slot};
+            if (fresh) reset_ray<true>(ray, camera_ray<MAD>(a.cam, glob, sample), a.cam.root_group, a.cam.root_local, 0u, RT_SKY_GROUP);
+            a.frame.next[index] = rt_index_pair{run_end_group<MAD>(key, ray, a), entry.slot};
             return;
         }
     }
@@ -1289,7 +1334,7 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
         // The samples that start here all enter the camera's root: a visit of its own, with the ray worked out in
         // registers and no pending entries.  A ray that comes out of an instance list at a model's root goes on below.
         uint32_t group_flags = 0;
-        done = visit_aabb<kAabbCap, kAabbThreads, false, true, true, PLACE>(uniform_value(key), ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid,
+        done = visit_aabb<kAabbCap, kAabbThreads, false, true, MAD, true, PLACE>(uniform_value(key), ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid,
                                                                      new_key, group_flags, sample);
         visit = done && (group_flags & RT_F_LOCAL0) && ((new_key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_AABB;
         asm volatile("" ::: "memory");  // the next visit reads what this one has stored to the slot
@@ -1302,7 +1347,7 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
             if (key != __builtin_amdgcn_readfirstlane(key)) continue;
             todo = false;
             const uint32_t g = uniform_value(key);  // every lane still here holds the same key
-            done = visit_aabb<kAabbCap, kAabbThreads, false, FREE, false, PLACE>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key,
+            done = visit_aabb<kAabbCap, kAabbThreads, false, FREE, MAD, false, PLACE>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key,
                                                                                   group_flags, 0, head_lds);
         }
         // Free schedule: a ray that has just been through a list of instances (the scene root) and whose
@@ -1332,7 +1377,7 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
             return;
         }
     }
-    if (FREE) new_key = run_end_group(new_key, ray, a);
+    if (FREE) new_key = run_end_group<MAD>(new_key, ray, a);
     a.frame.next[index_again] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 #if defined(RT_STAMPS) && RT_STAMPS == 3
     {
@@ -1344,31 +1389,31 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
 #endif
 }
 
-template <bool FREE>
+template <bool FREE, bool MAD>
 __attribute__((amdgpu_waves_per_eu(RT_AABB_WAVES, 8)))
 __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, uint32_t *spill_list)
 {
     __shared__ float s_pos[kAabbCap][kAabbThreads];
     __shared__ uint8_t s_idx[kAabbCap][kAabbThreads];
     __shared__ unsigned long long s_head[kAabbThreads];  // per lane: the head's two local ids (see visit_aabb)
-    process_aabb<FREE, uint8_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x]);
+    process_aabb<FREE, MAD, uint8_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x]);
 }
 
 // The same with two-byte places, for scenes with box lists of more than 256 boxes.
-template <bool FREE>
+template <bool FREE, bool MAD>
 __global__ __launch_bounds__(kAabbThreads) void k_process_aabb_wide(ProcessArgs a, uint32_t *spill_list)
 {
     __shared__ float s_pos[kAabbCap][kAabbThreads];
     __shared__ uint16_t s_idx[kAabbCap][kAabbThreads];
     __shared__ unsigned long long s_head[kAabbThreads];  // per lane: the head's two local ids (see visit_aabb)
-    process_aabb<FREE, uint16_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x]);
+    process_aabb<FREE, MAD, uint16_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x]);
 }
 
 // The box visits the main kernel left undone, one wave per ray: a lone lane scanning a 256-box list and
 // sorting 30 candidates in its own columns takes about 50 us, a wave sharing the work a few.
 constexpr int kBigThreads = 256, kBigBlocks = 256;
 
-template <bool FREE>
+template <bool FREE, bool MAD>
 __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a, const uint32_t *spill_list)
 {
     __shared__ float s_wave_pos[kBigThreads / 64][RT_MAX_HITS];   // per wave: the lists of wave_visit_one
@@ -1383,10 +1428,10 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
         const uint32_t g = uniform_value(ray->queue[0].group_id);
         uint32_t new_key = g;
         uint32_t group_flags;
-        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true, FREE, false, uint8_t>(g, ray, a, nullptr, nullptr, s_wave_pos[wave], s_wave_idx[wave], 0, tid,
+        visit_aabb<RT_MAX_QUEUE_LEN, kBigThreads, true, FREE, MAD, false, uint8_t>(g, ray, a, nullptr, nullptr, s_wave_pos[wave], s_wave_idx[wave], 0, tid,
                                                         new_key, group_flags);
         if (lane_id() == 0) {
-            if (FREE) new_key = run_end_group(new_key, ray, a);
+            if (FREE) new_key = run_end_group<MAD>(new_key, ray, a);
             a.frame.next[index] = rt_index_pair{new_key, slot};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1398,7 +1443,7 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
 // ---------------------------------------------------------------- process, everything but box groups
 
 // Leaf groups: triangle scan + hit commit.
-template <bool FREE>
+template <bool FREE, bool MAD>
 __attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, 8)))
 __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
 {
@@ -1416,15 +1461,16 @@ __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
         todo = false;
         const uint32_t g = uniform_value(key);  // every lane still here holds the same key
         MISC_STAMP(t_mesh0);
-        new_key = visit_mesh<FREE>(g, ray, a);
+        new_key = visit_mesh<FREE, MAD>(g, ray, a);
         MISC_STAMP(t_mesh1);
         MISC_STAMP_ADD(a.frame, 2, t_mesh0, t_mesh1);
     }
-    if (FREE) new_key = run_end_group(new_key, ray, a);
+    if (FREE) new_key = run_end_group<MAD>(new_key, ray, a);
     a.frame.next[index] = rt_index_pair{new_key, entry.slot};  // assign_index (ray-tracer.cl:171)
 }
 
 // Shader groups (spawn, sky, light, material) and parked entries.
+template <bool MAD>
 __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t pool)
 {
     const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1452,7 +1498,7 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
         switch ((g >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) {
         case RT_SH_SPAWN: {
             bool started;
-            new_key = init_ray<false>(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
+            new_key = init_ray<false, MAD>(a.cam, glob, ray, a.frame.hits, a.group_count, index + glob->g.pixel_offset, started);
             count_lanes(a.frame, kPrimarySpawned, started);
             break;
         }
@@ -1470,7 +1516,7 @@ __global__ __launch_bounds__(256) void k_process_shade(ProcessArgs a, uint32_t p
                 break;
             }
             const f32x4 color = *const_ptr<f32x4>(a.scene.grp + (g & kIdMask));
-            new_key = mat_shader<false>(ray, make_float4(color.x, color.y, color.z, color.w), glob->shading);
+            new_key = mat_shader<false, MAD>(ray, make_float4(color.x, color.y, color.z, color.w), glob->shading);
             count_lanes(a.frame, kShadowSpawned, true);
             break;
         }
@@ -1696,7 +1742,8 @@ void launch_init_frame(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
     k_init_groups<<<grid_for(c.group_count, 256), 256, 0, c.stream>>>(c.grp_data, c.group_count);
-    k_init_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
+    if (c.mad) k_init_rays<true><<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
+    else k_init_rays<false><<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
     (void)hipMemsetAsync(c.frame.area, 0, sizeof(float4) * size_t(c.area_size), c.stream);
 }
 
@@ -1707,32 +1754,45 @@ void launch_load_rays(const LaunchCtx &c, const rt_ray *rays, uint32_t n_rays)
     k_load_rays<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool, rays, n_rays);
 }
 
+template <bool FREE, bool MAD>
+static void process_boxes(const LaunchCtx &c, const ProcessArgs &a)
+{
+    const dim3 grid = grid_for(c.pool, kAabbThreads);
+    if (c.long_lists) k_process_aabb_wide<FREE, MAD><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+    else k_process_aabb<FREE, MAD><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
+    k_process_aabb_big<FREE, MAD><<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
+}
+
 void launch_process_boxes(const LaunchCtx &c)
 {
-    ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    const dim3 grid = grid_for(c.pool, kAabbThreads);
+    const ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
     if (c.free_schedule) {
-        if (c.long_lists) k_process_aabb_wide<true><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
-        else k_process_aabb<true><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
-        k_process_aabb_big<true><<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
+        if (c.mad) process_boxes<true, true>(c, a);
+        else process_boxes<true, false>(c, a);
     } else {
-        if (c.long_lists) k_process_aabb_wide<false><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
-        else k_process_aabb<false><<<grid, kAabbThreads, 0, c.stream>>>(a, c.spill_list);
-        k_process_aabb_big<false><<<kBigBlocks, kBigThreads, 0, c.stream>>>(a, c.spill_list);
+        if (c.mad) process_boxes<false, true>(c, a);
+        else process_boxes<false, false>(c, a);
     }
 }
 
 void launch_process_leaves(const LaunchCtx &c, hipStream_t stream)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    if (c.free_schedule) k_process_mesh<true><<<grid_for(c.pool, kMeshThreads), kMeshThreads, 0, stream>>>(a);
-    else k_process_mesh<false><<<grid_for(c.pool, kMeshThreads), kMeshThreads, 0, stream>>>(a);
+    const dim3 grid = grid_for(c.pool, kMeshThreads);
+    if (c.free_schedule) {
+        if (c.mad) k_process_mesh<true, true><<<grid, kMeshThreads, 0, stream>>>(a);
+        else k_process_mesh<true, false><<<grid, kMeshThreads, 0, stream>>>(a);
+    } else {
+        if (c.mad) k_process_mesh<false, true><<<grid, kMeshThreads, 0, stream>>>(a);
+        else k_process_mesh<false, false><<<grid, kMeshThreads, 0, stream>>>(a);
+    }
 }
 
 void launch_process_shade(const LaunchCtx &c)
 {
     ProcessArgs a{c.scene, c.frame, c.cam, c.group_count};
-    k_process_shade<<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
+    if (c.mad) k_process_shade<true><<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
+    else k_process_shade<false><<<grid_for(c.pool, 256), 256, 0, c.stream>>>(a, c.pool);
 }
 
 void launch_compact(const LaunchCtx &c, const rt_index_pair *sorted, rt_index_pair *dst)

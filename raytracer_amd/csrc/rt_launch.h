@@ -16,6 +16,7 @@ struct LaunchCtx {
     uint32_t pool, area_size, group_count;
     bool free_schedule;  // RT_FLAG_FREE_SCHEDULE: shading and spawn inside the visiting kernels, no shading launch
     bool long_lists;     // the scene has a box list of more than 256 boxes: the box kernel with two-byte places
+    bool mad;            // RT_FLAG_ARITH_MAD: the kernels that fuse their multiply-adds
 };
 
 void launch_init_frame(const LaunchCtx &c);
