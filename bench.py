@@ -82,6 +82,12 @@ def parse():
     p.add_argument("--serial", action="store_true",
                    help="keep every kernel of a step on one stream (as the stage-timing pass does): a rocprofv3 summary "
                         "of this run shows each kernel's duration alone")
+    p.add_argument("--collective", action="store_true",
+                   help="with --gpus 1: initialise torch.distributed (one rank) and run the frame gather of the N > 1 path -- the "
+                        "resolved band all-gathered with RCCL -- inside the timed region, as every rank of a multi-GPU run does")
+    p.add_argument("--spp", type=int, default=16,
+                   help="samples per pixel of the fixed-work measurement in the extras (a frame and its eight bands rendered to "
+                        "exactly this many samples per pixel, drain included)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo gathers through host memory: a rehearsal of the N > 1 path on a box with fewer GPUs than ranks")
     return p.parse_args()
@@ -177,6 +183,72 @@ def quick_rate(files, width, height, args, device, band=(0, 0), steps=32):
     return {"mrays_per_s": rays / dt / 1e6, "ms_per_step": dt * 1e3 / steps, "steady": steady, "pool": pool, "groups": sc.group_count}
 
 
+def time_to_spp(files, width, height, args, device, band, spp, band_pool=False):
+    """Fixed work: milliseconds to start spp * pixels samples of the band (or frame) and finish every one of them, frame
+    set-up included.  The pool is as large as the frame has pixels, as in the steady-state measurement, so a band of
+    a multi-GPU run keeps several samples of a pixel in flight at once.  Steps run at the production granularity
+    until all samples have been started, then at granularity 1 until no ray is in flight (the few samples of this
+    scene that circle for ever in the reference's automaton excepted).  band_pool: a pool of as many slots as the
+    band has pixels instead (shorter steps, a larger share of parked rays)."""
+    pool = S.L.align_up(width * (band[1] if band_pool and band[1] else height), S.L.SORT_TILE)
+    sc = S.build_scene(files, width, height, pool, band_first=band[0], band_rows=band[1], grid=args.grid)
+    limit = spp * sc.width * sc.height
+    rt = api.RayTracer(sc, device=device, warp_width=args.warp_width, sample_limit=limit, free_schedule=args.schedule == "free",
+                       shading=shading_flags(args), mad=args.arith == "mad")
+    rt.init_frame()
+    rt.make_step(2)
+    rt.sync()                                    # (first use of the context: graph capture)
+    t0 = time.perf_counter()
+    rt.init_frame()
+    steps = 0
+    while steps < 100000:
+        rt.make_step(16)
+        steps += 16
+        g = rt.global_data()[0]
+        # until every sample has been started -- or so few whole waves are left that the rest sits parked, which at this
+        # granularity would never move again
+        if int(g["pixel_offset"]) >= limit or int(g["ray_count"]) < rt.pool // 32:
+            break
+    rt.set_warp_width(1)
+    last, quiet, n = -1, 0, -1
+    while steps < 200000:
+        rt.make_step(8)
+        steps += 8
+        n = int(rt.global_data()["ray_count"][0])
+        if n == 0:
+            break
+        quiet = quiet + 1 if n == last and n <= 16 else 0
+        if quiet >= 3:  # the same few rays for 24 steps: those that never finish
+            break
+        last = n
+    rt.draw_frame_device()
+    dt = time.perf_counter() - t0
+    c = rt.counters()
+    rt.close()
+    return {"ms": dt * 1e3, "steps": steps, "rays": int(c["primary_spawned"]) + int(c["shadow_spawned"]), "left_in_flight": max(n, 0)}
+
+
+def fixed_work(files, width, height, args, device, gather_ms):
+    """A frame of --spp samples per pixel on this GPU, and each of its eight bands alone on this GPU as a rank of an
+    8-GPU run would render it: what tiling buys for a frame of fixed size."""
+    out = {"gather_ms": gather_ms,
+           "note": "one GPU, bands one after the other; every run ends with a drain of 100-200 steps at granularity 1 (a ray "
+                   "advances one node per step), which is why few samples per pixel scale badly; the gather time is this run's "
+                   "resolve + all-gather of one band (a single rank unless --gpus > 1), so the prediction leaves out what eight "
+                   "ranks on xGMI add"}
+    for spp in sorted({args.spp, 8 * args.spp}):
+        whole = time_to_spp(files, width, height, args, device, (0, 0), spp)
+        row = {"frame_ms": whole["ms"], "frame_steps": whole["steps"], "frame_mrays_per_s": whole["rays"] / whole["ms"] / 1e3}
+        for name, band_pool in (("full_pool_per_band", False), ("band_sized_pool", True)):
+            bands = [time_to_spp(files, width, height, args, device, tiling.band_of(r, 8, height), spp, band_pool) for r in range(8)]
+            slowest = max(b["ms"] for b in bands)
+            row[name] = {"band_ms": [round(b["ms"], 3) for b in bands], "band_steps": [b["steps"] for b in bands],
+                         "predicted_8gpu_frame_ms": slowest + gather_ms,
+                         "predicted_strong_scaling_efficiency": whole["ms"] / (8 * (slowest + gather_ms))}
+        out[f"{spp}_spp"] = row
+    return out
+
+
 def library_digest():
     path = os.environ.get("RT_HIP_LIB", api.HIP_LIB_PATH)
     with open(path, "rb") as f:
@@ -195,9 +267,15 @@ def main():
 
     dist = torch = None
     device = int(os.environ.get("RT_BENCH_DEVICE", local_rank))
-    if world > 1:
+    collective = world > 1 or args.collective
+    if collective:
         import torch
         import torch.distributed as dist
+        if world == 1:  # a single rank, set up as the launcher would for more
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             torch.cuda.set_device(device)
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -218,13 +296,13 @@ def main():
 
     band = frame = None
     max_rows = tiling.max_band_rows(world, args.height)
-    if world > 1:
+    if collective:
         band = torch.zeros((max_rows, args.width, 4), dtype=torch.uint8, device=tensor_device)
         frame = torch.zeros((world, max_rows, args.width, 4), dtype=torch.uint8, device=tensor_device)
     host_band = np.zeros((rows, args.width, 4), np.uint8)
 
     def resolve_and_gather():
-        if world > 1:
+        if collective:
             if tensor_device == "cuda":
                 rt.draw_frame_device(band.data_ptr())
             else:
@@ -236,7 +314,7 @@ def main():
 
     def barrier():
         rt.sync()
-        if world > 1:
+        if collective:
             if tensor_device == "cuda":
                 torch.cuda.synchronize()
             dist.barrier()
@@ -280,7 +358,7 @@ def main():
         dk = {k: int(c2[k]) - int(c1[k]) for k in keys}
     rt.set_profiling(0)
     local = np.array([dt, d["primary_spawned"], d["shadow_spawned"], d["box_tests"], d["tri_tests"]], np.float64)
-    if world > 1:
+    if collective:
         t = torch.tensor(local, dtype=torch.float64, device=tensor_device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -340,7 +418,7 @@ def main():
                                    + f", {args.width}x{args.height}, {pool} ray slots per GPU, "
                                    + ("primary + shadow rays" if args.shading == "reference" else
                                       f"primary rays, {args.bounces} {args.shading} bounces, shadow rays"),
-                       "tiling": f"{world} row band(s), RGBA8 all-gather per frame" if world > 1 else "single GPU",
+                       "tiling": f"{world} row band(s), RGBA8 all-gather per frame ({args.backend})" if collective else "single GPU",
                        "warp_width": args.warp_width, "schedule": args.schedule, "arithmetic": args.arith, "groups": sc.group_count,
                        "tri_threshold": args.tri_threshold, "aabb_threshold": args.aabb_threshold},
             "mrays_primary_only": float(total[1]) / elapsed / 1e6,
@@ -369,6 +447,7 @@ def main():
                     "predicted_8gpu_mrays_per_s": total,
                     "predicted_scaling_efficiency": total / 8 / out["value"],
                     "note": "rays of all bands per step of the slowest band, over 8 x the single-GPU rate; excludes the all-gather"}
+                extra["fixed_work"] = fixed_work(files, args.width, args.height, args, device, gather_ms)
             except Exception as e:
                 extra["error"] = str(e)
             out["extra"] = extra
@@ -379,7 +458,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     rt.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -209,6 +209,11 @@ int rt_sync(rt_ctx *ctx);
  * dst == NULL and dst_is_device != 0 the image stays in the context's own device buffer
  * (rt_image_device), as the reference's stays in its GL texture. */
 int rt_resolve_rgba8(rt_ctx *ctx, void *dst, int dst_is_device);
+/* The same resolve into device memory (dst, or the context's own image when dst is NULL), only enqueued on the
+ * context's stream: the call does not wait, as the reference's clEnqueueNDRangeKernel of update_image does not
+ * (main.cpp:485; its glFinish and release come later).  A host that drives several contexts enqueues all their
+ * resolves and then waits for each (rt_sync), so that the GPUs resolve side by side. */
+int rt_resolve_rgba8_enqueue(rt_ctx *ctx, void *dst_device);
 /* Device address of the context's RGBA8 image (width*height*4 bytes), valid until rt_destroy. */
 void *rt_image_device(rt_ctx *ctx);
 

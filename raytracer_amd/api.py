@@ -25,7 +25,7 @@ def shading_flags(mode, bounces, seed=0x5EED):
 
 EXPORTS = (
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_init_frame", "rt_step", "rt_set_warp_width", "rt_sync",
-    "rt_resolve_rgba8", "rt_read_area", "rt_current_ray", "rt_get_global", "rt_get_counters", "rt_sort_pairs",
+    "rt_resolve_rgba8", "rt_resolve_rgba8_enqueue", "rt_read_area", "rt_current_ray", "rt_get_global", "rt_get_counters", "rt_sort_pairs",
     "rt_compact_groups", "rt_dump_state", "rt_read_hits", "rt_trace_closest", "rt_set_profiling",
     "rt_get_stage_times", "rt_debug_stamps", "rt_sort_pairs_static", "rt_image_device", "rt_stream", "rt_status_string", "rt_last_error",
 )
@@ -64,6 +64,7 @@ def hip_lib():
             "rt_set_warp_width": (i, [vp, u32]),
             "rt_sync": (i, [vp]),
             "rt_resolve_rgba8": (i, [vp, vp, i]),
+            "rt_resolve_rgba8_enqueue": (i, [vp, vp]),
             "rt_read_area": (i, [vp, vp]),
             "rt_current_ray": (i, [vp, C.POINTER(u32)]),
             "rt_get_global": (i, [vp, vp]),
@@ -150,6 +151,10 @@ class RayTracer:
     def draw_frame_device(self, device_ptr=None):
         """Resolves into device memory: the caller's buffer, or the context's own image (image_device)."""
         self._check(self.lib.rt_resolve_rgba8(self.h, C.c_void_p(device_ptr) if device_ptr else None, 1))
+
+    def enqueue_draw_frame_device(self, device_ptr=None):
+        """The same without waiting for it (rt_sync does)."""
+        self._check(self.lib.rt_resolve_rgba8_enqueue(self.h, C.c_void_p(device_ptr) if device_ptr else None))
 
     def image_device(self):
         return self.lib.rt_image_device(self.h)

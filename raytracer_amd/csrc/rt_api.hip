@@ -757,6 +757,14 @@ int rt_resolve_rgba8(rt_ctx *c, void *dst, int dst_is_device)
     return RT_OK;
 }
 
+int rt_resolve_rgba8_enqueue(rt_ctx *c, void *dst_device)
+{
+    if (!c) return RT_ERR_INVALID_VALUE;
+    RT_HIP(c, hipSetDevice(c->cfg.device));
+    launch_resolve(launch_ctx(c), dst_device ? dst_device : c->rgba);
+    return check_launch(c, "resolve");
+}
+
 int rt_read_area(rt_ctx *c, float *dst)
 {
     if (!c || !dst) return RT_ERR_INVALID_VALUE;

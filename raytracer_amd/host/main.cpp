@@ -3,7 +3,7 @@
 // line "Frame ready in X s, N rays, Y MR/s." (main.cpp:534-540).  The image goes to a PPM file.
 //
 //   rt_main [--device N | --gpus N | --devices a,b,...] [--rccl] [--width W] [--height H] [--rays R]
-//           [--frames F] [--steps S] [--spp K] [--models a.ply;b.ply] [--warp W] [--schedule free|reference]
+//           [--frames F] [--steps S] [--spp K] [--models a.ply;b.ply] [--warp W] [--schedule free|reference] [--arith strict|mad]
 //           [--band-first ROW --band-rows ROWS] [--out image.ppm]
 //
 // --gpus N renders on devices 0..N-1, one row band each, and gathers the bands with RCCL once per frame
@@ -32,7 +32,7 @@ double now_seconds()
 
 const char *kUsage =
     "Usage: rt_main [--device N | --gpus N | --devices a,b,...] [--rccl] [--width W] [--height H] [--rays R] [--frames F]"
-    " [--steps S] [--spp K] [--models a.ply;b.ply] [--warp W] [--schedule free|reference]"
+    " [--steps S] [--spp K] [--models a.ply;b.ply] [--warp W] [--schedule free|reference] [--arith strict|mad]"
     " [--band-first ROW --band-rows ROWS] [--out image.ppm]";
 
 // What the frame loop needs from one renderer or from a tiled set of them.
@@ -88,13 +88,20 @@ int main(int argc, char **argv)
         else if (arg == "--warp") warp = uint32_t(std::atoi(need()));
         else if (arg == "--band-first") band_first = uint32_t(std::atoi(need()));
         else if (arg == "--band-rows") band_rows = uint32_t(std::atoi(need()));
-        else if (arg == "--schedule") {
+        else if (arg == "--arith") {
+            const std::string s = need();
+            if (s != "strict" && s != "mad") {
+                std::cout << kUsage << std::endl;
+                return 2;
+            }
+            flags = (flags & ~RT_FLAG_ARITH_MAD) | (s == "mad" ? RT_FLAG_ARITH_MAD : 0u);
+        } else if (arg == "--schedule") {
             const std::string s = need();
             if (s != "free" && s != "reference") {
                 std::cout << kUsage << std::endl;
                 return 2;
             }
-            flags = s == "free" ? RT_FLAG_FREE_SCHEDULE : 0;
+            flags = (flags & ~RT_FLAG_FREE_SCHEDULE) | (s == "free" ? RT_FLAG_FREE_SCHEDULE : 0u);
         } else if (arg == "--out") out = need();
         else {
             std::cout << kUsage << std::endl;
@@ -102,6 +109,15 @@ int main(int argc, char **argv)
         }
     }
     if (!rays) rays = width * height;  // main.cpp:516
+    if (!width || !height || uint64_t(width) * height > 0x7FFFFFFFull) {
+        std::cout << "The image must have between 1 and 2^31 - 1 pixels" << std::endl;
+        return 2;
+    }
+    // the sample limit is a 32-bit count (sample ids are): refuse what does not fit instead of wrapping
+    if (uint64_t(spp) * width * (band_rows ? band_rows : height) > 0x7FFFFFFFull) {
+        std::cout << "--spp " << spp << " at " << width << "x" << (band_rows ? band_rows : height) << " exceeds 2^31 - 1 samples" << std::endl;
+        return 2;
+    }
     std::vector<std::string> files;
     for (size_t at = 0; at <= models.size();) {
         size_t end = models.find(';', at);

@@ -83,6 +83,16 @@ bool RayTracer::resolve_to_device(void *device_image)
     return report("Cannot resolve image", rt_resolve_rgba8(ctx_, device_image, 1));
 }
 
+bool RayTracer::enqueue_resolve_to_device(void *device_image)
+{
+    return report("Cannot resolve image", rt_resolve_rgba8_enqueue(ctx_, device_image));
+}
+
+bool RayTracer::sync()
+{
+    return report("Cannot finish", rt_sync(ctx_));
+}
+
 void *RayTracer::stream()
 {
     return rt_stream(ctx_);

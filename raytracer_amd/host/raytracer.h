@@ -38,6 +38,8 @@ public:
     bool draw_frame();
     // The same resolve into a device buffer of width * height() * 4 bytes on this context's GPU; no host copy.
     bool resolve_to_device(void *device_image);
+    bool enqueue_resolve_to_device(void *device_image);  // the same, not waited for
+    bool sync();                                          // waits until the context's stream is idle
     void *stream();                      // the context's hipStream_t
     uint32_t rays_in_flight();           // GlobalData.ray_count
     uint32_t current_ray();

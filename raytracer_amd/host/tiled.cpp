@@ -41,6 +41,15 @@ bool TiledRenderer::init(const std::vector<int> &devices)
 {
     const uint32_t n = uint32_t(devices.size());
     if (!n || n > height_) return fail("Cannot tile the frame", "need between 1 and `height` bands");
+    int present = 0;
+    if (hipGetDeviceCount(&present) != hipSuccess || present <= 0) return fail("Cannot tile the frame", "no GPU");
+    const std::set<int> distinct(devices.begin(), devices.end());
+    for (int d : distinct)
+        if (d < 0 || d >= present) return fail("Cannot tile the frame", "device ordinal out of range");
+    // one band per GPU (gathered with RCCL), or every band on ONE GPU (a rehearsal, gathered by copies on it)
+    if (distinct.size() != n && distinct.size() != 1) return fail("Cannot tile the frame", "repeat one device ordinal or none");
+    if (sample_limit_per_pixel && uint64_t(sample_limit_per_pixel) * width_ * ((height_ + n - 1) / n) > 0x7FFFFFFFull)
+        return fail("Cannot tile the frame", "samples per band exceed 2^31 - 1");
     device_ = devices;
     max_rows_ = (height_ + n - 1) / n;
     const size_t band_bytes = max_rows_ * width_ * 4;
@@ -65,7 +74,7 @@ bool TiledRenderer::init(const std::vector<int> &devices)
             return fail("Cannot allocate the band images", hipGetErrorString(hipGetLastError()));
     }
     // RCCL needs one rank per distinct device; bands that share a GPU (a rehearsal) are gathered by copies.
-    if (std::set<int>(devices.begin(), devices.end()).size() == n) {
+    if (distinct.size() == n) {
         std::vector<ncclComm_t> comms(n);
         const ncclResult_t rc = ncclCommInitAll(comms.data(), int(n), devices.data());
         if (rc != ncclSuccess) return fail("Cannot create the RCCL communicators", ncclGetErrorString(rc));
@@ -100,8 +109,8 @@ bool TiledRenderer::set_warp_width(uint32_t w)
 bool TiledRenderer::draw_frame()
 {
     const size_t n = band_.size(), band_bytes = max_rows_ * width_ * 4;
-    for (size_t i = 0; i < n; i++)
-        if (!band_[i]->resolve_to_device(band_image_[i])) return false;  // returns once the band's stream is idle
+    for (size_t i = 0; i < n; i++)  // enqueued only: the GPUs resolve side by side, and the gather is ordered behind each band's resolve
+        if (!band_[i]->enqueue_resolve_to_device(band_image_[i])) return false;
     if (!comms_.empty()) {
         // one collective per frame, on the resolved image; every rank receives the whole frame
         ncclResult_t rc = ncclGroupStart();
@@ -115,9 +124,13 @@ bool TiledRenderer::draw_frame()
         if (hipSetDevice(device_[0]) != hipSuccess || hipStreamSynchronize(static_cast<hipStream_t>(band_[0]->stream())) != hipSuccess)
             return fail("Cannot finish the gather", hipGetErrorString(hipGetLastError()));
     } else {
-        for (size_t i = 0; i < n; i++)
-            if (hipMemcpy(static_cast<char *>(frame_image_[0]) + i * band_bytes, band_image_[i], band_bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+        // bands that share a GPU (init() accepts nothing else without RCCL): copies on that GPU
+        for (size_t i = 0; i < n; i++) {
+            if (!band_[i]->sync()) return false;
+            if (hipSetDevice(device_[0]) != hipSuccess ||
+                hipMemcpy(static_cast<char *>(frame_image_[0]) + i * band_bytes, band_image_[i], band_bytes, hipMemcpyDeviceToDevice) != hipSuccess)
                 return fail("Cannot gather the bands", hipGetErrorString(hipGetLastError()));
+        }
     }
     if (hipMemcpy(padded_.data(), frame_image_[0], band_bytes * n, hipMemcpyDeviceToHost) != hipSuccess)
         return fail("Cannot read the frame", hipGetErrorString(hipGetLastError()));

@@ -29,7 +29,8 @@ public:
     std::vector<std::string> model_files;
     uint32_t warp_width = 64, sample_limit_per_pixel = 0, flags = 0, grid = 0;
 
-    // One band per entry of `devices` (HIP ordinals; an ordinal may repeat).
+    // One band per entry of `devices` (HIP ordinals): all distinct (one band per GPU, gathered with RCCL) or all the
+    // same (a rehearsal of the bands on one GPU, gathered by copies on it).
     bool init(const std::vector<int> &devices);
     bool init_frame();
     bool make_step();
