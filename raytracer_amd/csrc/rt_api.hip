@@ -526,6 +526,11 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
         if (((id >> RT_GROUP_TR_SHIFT) & RT_GROUP_TR_MASK) == RT_TR_ORTHO) any_ortho = true;
         if (gi >= n_groups) return fail(c, RT_ERR_INVALID_VALUE, "%s refers to group %u of %zu", where, gi, n_groups);
         if (sh != RT_SH_AABB && sh != RT_SH_MESH) return fail(c, RT_ERR_INVALID_VALUE, "%s: group %u is not a box or mesh group", where, gi);
+        // The reference's transform() sets the local ray for tr_identity and tr_ortho only; tr_affine is an empty "TODO" case
+        // and tr_none has none (shader.cl:45-72), so a ray entering such a group there is scanned with an unset ray.
+        const uint32_t tr = (id >> RT_GROUP_TR_SHIFT) & RT_GROUP_TR_MASK;
+        if (tr != RT_TR_IDENTITY && tr != RT_TR_ORTHO)
+            return fail(c, RT_ERR_UNSUPPORTED, "%s: group %u has transform type %u; the reference defines a result for tr_identity and tr_ortho only", where, gi, tr);
         if (kind[gi] == 0xFF) {
             kind[gi] = uint8_t(sh);
             work.push_back(id);

@@ -279,8 +279,9 @@ def test_incoherent_rays_in_a_grid_of_instances(standin_ply):
 
 
 def test_instance_list_longer_than_256_boxes():
-    """A 7x7x7 grid puts 343 boxes under the scene root: more than the box kernel's one-byte places hold, so
-    every root visit is done by the one-ray-per-wave kernel.  Hits bit-exact against the oracle, either schedule."""
+    """A 7x7x7 grid puts 343 boxes under the scene root: more than the box kernel's one-byte places hold, so the scene
+    runs the box kernel with two-byte places, which scans the root's list in two parts of at most 256 boxes.  Hits
+    bit-exact against the oracle, either schedule."""
     from oracle import pyoracle as O
     sc = S.build_scene([S.BUNNY], 64, 64, 16384, grid=7)
     root = int(sc.data["cam"]["root_group"][0]) & L.GROUP_ID_MASK
@@ -316,6 +317,10 @@ def test_api_errors(bunny_scene_64):
     bad.aabbs["group_id"][0] = 0x40FFFFF0     # box pointing outside the group table
     with pytest.raises(api.RtError, match="RT_ERR_INVALID_VALUE"):
         rt.upload(bad)
+    affine = S.build_scene([S.BUNNY], 64, 64, 8192, n_obj=4)
+    affine.aabbs["group_id"][0] = (affine.aabbs["group_id"][0] & ~np.uint32(0xF << 24)) | np.uint32(L.TR_AFFINE << 24)
+    with pytest.raises(api.RtError, match="RT_ERR_UNSUPPORTED"):
+        rt.upload(affine)                     # tr_affine is an empty case in the reference (shader.cl:69-71)
     other = S.build_scene([S.BUNNY], 32, 32, 8192, n_obj=4)
     with pytest.raises(api.RtError, match="does not match"):
         rt.upload(other)                      # camera size differs from the context
