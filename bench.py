@@ -162,12 +162,13 @@ def settle(rt, steps):
     return done, False
 
 
-def quick_rate(files, width, height, args, device, band=(0, 0), steps=32):
+def quick_rate(files, width, height, args, device, band=(0, 0), steps=32, arith=None, aabb_threshold=None):
     """Mrays/s and ms/step of one more configuration on this GPU (settled, `steps` timed steps)."""
     pool = S.L.align_up(width * height, S.L.SORT_TILE)
-    sc = S.build_scene(files, width, height, pool, band_first=band[0], band_rows=band[1], grid=args.grid)
+    sc = S.build_scene(files, width, height, pool, band_first=band[0], band_rows=band[1], grid=args.grid,
+                       tri_threshold=args.tri_threshold, aabb_threshold=aabb_threshold or args.aabb_threshold)
     rt = api.RayTracer(sc, device=device, warp_width=args.warp_width, free_schedule=args.schedule == "free",
-                       shading=shading_flags(args), mad=args.arith == "mad")
+                       shading=shading_flags(args), mad=(arith or args.arith) == "mad")
     rt.init_frame()
     _, steady = settle(rt, args.settle)
     rt.sync()
@@ -180,7 +181,8 @@ def quick_rate(files, width, height, args, device, band=(0, 0), steps=32):
     c1 = rt.counters()
     rt.close()
     rays = int(c1["primary_spawned"]) - int(c0["primary_spawned"]) + int(c1["shadow_spawned"]) - int(c0["shadow_spawned"])
-    return {"mrays_per_s": rays / dt / 1e6, "ms_per_step": dt * 1e3 / steps, "steady": steady, "pool": pool, "groups": sc.group_count}
+    return {"mrays_per_s": rays / dt / 1e6, "ms_per_step": dt * 1e3 / steps, "steady": steady, "pool": pool, "groups": sc.group_count,
+            "box_tests_per_ray": (int(c1["box_tests"]) - int(c0["box_tests"])) / max(rays, 1)}
 
 
 def time_to_spp(files, width, height, args, device, band, spp, band_pool=False):
@@ -435,6 +437,13 @@ def main():
             rt.close()  # one full-size pool at a time
             extra = {"configs": {}}
             try:
+                other = "strict" if args.arith == "mad" else "mad"
+                extra["configs"][f"same workload, --arith {other}"] = quick_rate(files, args.width, args.height, args, device, arith=other)
+                # a narrower hierarchy over the same leaves (inner groups of 8-15 and of 16-31 boxes instead of 128-255)
+                for threshold in (8, 16):
+                    if threshold != args.aabb_threshold:
+                        extra["configs"][f"same workload, --aabb-threshold {threshold}"] = quick_rate(
+                            files, args.width, args.height, args, device, aabb_threshold=threshold)
                 if (args.width, args.height) != (3840, 2160):
                     extra["configs"]["3840x2160, same scene"] = quick_rate(files, 3840, 2160, args, device)
                 if args.scene != "bunny":

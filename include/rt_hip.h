@@ -249,7 +249,11 @@ int rt_sort_pairs(rt_ctx *ctx, const rt_index_pair *in, rt_index_pair *out,
  * the kernels are enqueued on `stream` (a hipStream_t of that device, NULL = the default stream).
  * count must be a multiple of RT_SORT_TILE and at most RT_SORT_STATIC_MAX_PAIRS (RT_ERR_UNSUPPORTED
  * beyond).  All calls on one GPU share that GPU's workspace: calls that may overlap in time on the
- * same GPU (different streams or threads) race and must be serialised by the caller. */
+ * same GPU (different streams or threads) race and must be serialised by the caller.
+ * Under stream capture: the first call on a device looks the workspace's address up (a module load, which is
+ * not capturable), so make one call on that device -- or create an rt_ctx on it -- before capturing; and the
+ * value of n is stored by a captured launch as it was at capture time (count, n and group_count are baked into
+ * the graph like any other kernel argument). */
 #define RT_SORT_STATIC_MAX_PAIRS 1048576u
 int rt_sort_pairs_static(const rt_index_pair *in_dev, rt_index_pair *out_dev,
                          uint32_t count, uint32_t n, uint32_t group_count, void *stream);

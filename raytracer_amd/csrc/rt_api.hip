@@ -434,7 +434,9 @@ int rt_create(const rt_config *cfg, rt_ctx **out)
     *out = c;  // so that rt_last_error / rt_destroy work on a half-built context
 
     RT_HIP(c, hipSetDevice(cfg->device));
-    RT_HIP(c, sort_static_setup(nullptr));  // rt_sort_pairs_static's workspace on this device
+    (void)sort_static_setup(nullptr);  // rt_sort_pairs_static's workspace on this device, looked up while no stream is being
+                                       // captured; that entry point reports a failure itself, a context does not need it
+    (void)hipGetLastError();
     RT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->use_graph = getenv("RT_NO_GRAPH") == nullptr;
     if (!getenv("RT_NO_OVERLAP")) {
@@ -644,11 +646,14 @@ int rt_upload_scene(rt_ctx *c, const rt_global_data *data, const rt_group *grp, 
     RT_HIP(c, dev_alloc(c->tri_rec, dev_rec.size()));
     RT_HIP(c, dev_alloc(c->grp_data, G));
     RT_HIP(c, alloc_compact(c->compact, G));
-    if (c->free_schedule && G <= kFusedMaxGroups) {
+    // One counter per group in the rank kernel's LDS: where the device grants a workgroup that much (160 KB on gfx950, so
+    // up to kFusedMaxGroups groups); otherwise, and for larger scenes, the plain-order sort and the two compaction kernels.
+    if (c->free_schedule && G <= kFusedMaxGroups && fused_setup(G) == hipSuccess) {
         RT_HIP(c, dev_alloc(c->fused.ghist, size_t(G) * fused_hist_slices()));
         RT_HIP(c, dev_alloc(c->fused.block_main, compact_group_blocks(G)));
         RT_HIP(c, hipMemset(c->fused.ghist, 0, sizeof(uint32_t) * size_t(G) * fused_hist_slices()));
-        RT_HIP(c, fused_setup(G));
+    } else {
+        (void)hipGetLastError();
     }
     RT_HIP(c, hipMemset(c->grp, 0, sizeof(rt_group) * size_t(G)));
     RT_HIP(c, hipMemset(c->grp_data, 0, sizeof(rt_group_data) * size_t(G)));

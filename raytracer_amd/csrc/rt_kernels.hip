@@ -1283,10 +1283,9 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 // (24 instead of 20 KB of LDS per workgroup for the columns, i.e. six instead of seven workgroups per CU).
 template <bool FREE, bool MAD, typename PLACE>
 __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spill_list, float (*s_pos)[kAabbThreads],
-                                             PLACE (*s_idx)[kAabbThreads], uint32_t head_lds)
+                                             PLACE (*s_idx)[kAabbThreads], uint32_t head_lds, uint32_t first_index, uint32_t tid)
 {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t index = blockIdx.x * blockDim.x + tid;
+    const uint32_t index = first_index + tid;
     DevGlobal *glob = a.frame.glob;
 #if defined(RT_STAMPS) && RT_STAMPS == 3
     unsigned long long trace_t0;
@@ -1365,7 +1364,7 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
     // every store of the visit, one counter for loads and stores)
     uint32_t tid_again = tid;
     asm volatile("" : "+v"(tid_again));
-    const uint32_t index_again = blockIdx.x * blockDim.x + tid_again;
+    const uint32_t index_again = first_index + tid_again;
     const unsigned long long spilled = __ballot(!done);
     if (spilled) {
         uint32_t base = 0;
@@ -1396,7 +1395,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb(ProcessArgs a, ui
     __shared__ float s_pos[kAabbCap][kAabbThreads];
     __shared__ uint8_t s_idx[kAabbCap][kAabbThreads];
     __shared__ unsigned long long s_head[kAabbThreads];  // per lane: the head's two local ids (see visit_aabb)
-    process_aabb<FREE, MAD, uint8_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x]);
+    process_aabb<FREE, MAD, uint8_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x], blockIdx.x * blockDim.x, threadIdx.x);
 }
 
 // The same with two-byte places, for scenes with box lists of more than 256 boxes.
@@ -1406,7 +1405,7 @@ __global__ __launch_bounds__(kAabbThreads) void k_process_aabb_wide(ProcessArgs 
     __shared__ float s_pos[kAabbCap][kAabbThreads];
     __shared__ uint16_t s_idx[kAabbCap][kAabbThreads];
     __shared__ unsigned long long s_head[kAabbThreads];  // per lane: the head's two local ids (see visit_aabb)
-    process_aabb<FREE, MAD, uint16_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x]);
+    process_aabb<FREE, MAD, uint16_t>(a, spill_list, s_pos, s_idx, (uint32_t)(uintptr_t)&s_head[threadIdx.x], blockIdx.x * blockDim.x, threadIdx.x);
 }
 
 // The box visits the main kernel left undone, one wave per ray: a lone lane scanning a 256-box list and
@@ -1444,10 +1443,18 @@ __global__ __launch_bounds__(kBigThreads) void k_process_aabb_big(ProcessArgs a,
 
 // Leaf groups: triangle scan + hit commit.
 template <bool FREE, bool MAD>
+__device__ __forceinline__ void process_mesh(const ProcessArgs &a, uint32_t index);
+
+template <bool FREE, bool MAD>
 __attribute__((amdgpu_waves_per_eu(RT_MESH_WAVES, 8)))
 __global__ __launch_bounds__(kMeshThreads) void k_process_mesh(ProcessArgs a)
 {
-    const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+    process_mesh<FREE, MAD>(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+template <bool FREE, bool MAD>
+__device__ __forceinline__ void process_mesh(const ProcessArgs &a, uint32_t index)
+{
     const rt_index_pair entry = a.frame.index[index];  // requested before the live count has arrived
     const uint32_t key = entry.key;
     if (index >= step_constant(&a.frame.glob->g.ray_count)) return;

@@ -530,6 +530,11 @@ hipError_t fused_setup(uint32_t group_count)
 {
     const uint32_t bytes = fused_hist_lds_bytes(group_count);
     if (bytes <= 48 * 1024) return hipSuccess;
+    int device = 0, limit = 0;
+    hipError_t err = hipGetDevice(&device);
+    if (err == hipSuccess) err = hipDeviceGetAttribute(&limit, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+    if (err != hipSuccess) return err;
+    if (bytes > uint32_t(limit)) return hipErrorInvalidValue;  // the caller takes the sort path
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_rank), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
@@ -621,6 +626,7 @@ extern "C" int rt_sort_pairs_static(const rt_index_pair *in_dev, rt_index_pair *
     if (rtd::sort_static_setup(&where) != hipSuccess) return RT_ERR_HIP;
     StaticSortScratch *ws = static_cast<StaticSortScratch *>(where);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();  // an error left behind by an earlier, unrelated call is not this call's
     // Nothing in the workspace has to start at zero: every pass overwrites the counts of the tiles it
     // reads and all totals before using them, and tmp is written before it is read.
     k_store_u32<<<1, 1, 0, s>>>(&ws->n, n);

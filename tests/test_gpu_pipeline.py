@@ -449,3 +449,28 @@ def test_cpp_host_tiles_the_frame(tmp_path):
     one, log = run(["--rccl"], "rccl.ppm")
     assert "1 band(s), gathered with RCCL" in log
     assert np.abs(one.astype(int) - full.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("models", [13, 33])
+def test_free_schedule_with_many_groups(models):
+    """13 separately built models give 13,824 groups: the rank kernel's per-group counters then need more than the
+    48 KB of LDS a workgroup gets without asking (54 KB, granted on gfx950).  33 models give 34,304 groups, beyond what
+    the rank kernel holds at all: such a scene takes the plain-order sort and the two compaction kernels.  Finished
+    frames against the oracle on either path."""
+    from oracle import pyoracle as O
+    from test_oracle_pipeline import run_to_completion as oracle_to_completion
+    W, Hh = 96, 64
+    limit = W * Hh
+    sc = S.build_scene([S.BUNNY] * models, W, Hh, 8192, n_obj=2 * models)
+    assert (12288 < sc.group_count <= 32768) if models == 13 else sc.group_count > 32768
+    o = O.Oracle(sc, warp_width=32, sample_limit=limit, hit_capacity=limit)
+    oracle_to_completion(o, steps_parked=24)
+    rt = api.RayTracer(sc, warp_width=64, sample_limit=limit, hit_capacity=limit, free_schedule=True)
+    run_to_completion(rt, steps_parked=12)
+    assert H.same_bytes(rt.hits(), o.hits)
+    assert np.allclose(rt.area(), o.area, rtol=1e-5, atol=1e-6)
+    assert np.abs(rt.draw_frame().astype(int) - o.resolve_rgba8().astype(int)).max() <= 1
+    c, oc = rt.counters(), o.counters()
+    for k in ("primary_spawned", "shadow_spawned"):
+        assert int(c[k]) == int(oc[k]), k
+    rt.close(); o.close()

@@ -2,7 +2,7 @@
 # Developer tool: kernel timeline of a few steps (start/end per dispatch) to look at idle gaps.
 out=$PWD/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/trace -o t -- python3 -u /root/repo/bench.py --cpu-seconds 0 --no-extras --steps 16 --warmup 96 > /dev/null 2> $out/trace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/trace -o t -- python3 -u /root/repo/bench.py --cpu-seconds 0 --no-extras --steps 16 --warmup 96 ${BENCH_FLAGS} > /dev/null 2> $out/trace.err
 python3 - <<'PY'
 import csv, glob, os
 f = glob.glob(os.path.join(os.environ.get('OUT', '/root/repo/gpurun_out'), 'trace', '**', '*kernel_trace.csv'), recursive=True)[0]
