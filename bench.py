@@ -67,9 +67,10 @@ def parse():
     p.add_argument("--schedule", default="free", choices=["free", "reference"],
                    help="free: RT_FLAG_FREE_SCHEDULE (any processing order, same per-sample results); reference: every "
                         "step reproduces the reference's make_step state exactly")
-    p.add_argument("--arith", default="strict", choices=["strict", "mad"],
-                   help="strict: every product and sum rounded on its own; mad: multiply-adds fused at the stated places "
-                        "(RT_FLAG_ARITH_MAD; the reference builds its kernels with -cl-mad-enable, main.cpp:253)")
+    p.add_argument("--arith", default="mad", choices=["strict", "mad"],
+                   help="mad: multiply-adds fused at the stated places (RT_FLAG_ARITH_MAD), which is how the reference builds its "
+                        "kernels (-cl-mad-enable, main.cpp:253); strict: every product and sum rounded on its own.  Either way the "
+                        "HIP path equals the oracle of the same mode bit for bit; the other mode's rate is in the extras")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 disables it)")
     p.add_argument("--dragon", default=os.environ.get("RT_DRAGON_PLY", ""), help="path to dragon_vrip.ply if available")
     p.add_argument("--stage-timers", default="after", choices=["after", "timed"],
@@ -189,8 +190,8 @@ def time_to_spp(files, width, height, args, device, band, spp, band_pool=False):
     """Fixed work: milliseconds to start spp * pixels samples of the band (or frame) and finish every one of them, frame
     set-up included.  The pool is as large as the frame has pixels, as in the steady-state measurement, so a band of
     a multi-GPU run keeps several samples of a pixel in flight at once.  Steps run at the production granularity
-    until all samples have been started, then at granularity 1 until no ray is in flight (the few samples of this
-    scene that circle for ever in the reference's automaton excepted).  band_pool: a pool of as many slots as the
+    until all samples have been started, then at a granularity that goes down to 1 with the number of rays left until
+    none is in flight (the few samples of this scene that circle for ever in the reference's automaton excepted).  band_pool: a pool of as many slots as the
     band has pixels instead (shorter steps, a larger share of parked rays)."""
     pool = S.L.align_up(width * (band[1] if band_pool and band[1] else height), S.L.SORT_TILE)
     sc = S.build_scene(files, width, height, pool, band_first=band[0], band_rows=band[1], grid=args.grid)
@@ -211,16 +212,21 @@ def time_to_spp(files, width, height, args, device, band, spp, band_pool=False):
         # granularity would never move again
         if int(g["pixel_offset"]) >= limit or int(g["ray_count"]) < rt.pool // 32:
             break
-    rt.set_warp_width(1)
-    last, quiet, n = -1, 0, -1
+    # The drain: whole waves of one group become rare as the pool empties, so the granularity of the re-packing goes down
+    # with the live count -- at granularity 1 from the start every wave would hold a dozen groups and visit them in turn.
+    last, quiet, n, width = -1, 0, -1, args.warp_width
     while steps < 200000:
         rt.make_step(8)
         steps += 8
         n = int(rt.global_data()["ray_count"][0])
-        if n == 0:
+        if n == 0 and width == 1:
             break
+        want = 64 if n > rt.pool // 4 else 16 if n > rt.pool // 16 else 4 if n > rt.pool // 128 else 1
+        if want < width:
+            width = want
+            rt.set_warp_width(width)
         # the same few rays for 24 steps: those that never finish (about one sample in two million on this scene)
-        quiet = quiet + 1 if n == last and n <= max(16, limit // 250000) else 0
+        quiet = quiet + 1 if n == last and width == 1 and n <= max(16, limit // 250000) else 0
         if quiet >= 3:
             break
         last = n
@@ -235,8 +241,9 @@ def fixed_work(files, width, height, args, device, gather_ms):
     """A frame of --spp samples per pixel on this GPU, and each of its eight bands alone on this GPU as a rank of an
     8-GPU run would render it: what tiling buys for a frame of fixed size."""
     out = {"gather_ms": gather_ms,
-           "note": "one GPU, bands one after the other; every run ends with a drain of 100-200 steps at granularity 1 (a ray "
-                   "advances one node per step), which is why few samples per pixel scale badly; the gather time is this run's "
+           "note": "one GPU, bands one after the other; every run ends with a drain of 100-200 steps (a ray advances one node "
+                   "per step, and with few rays left a wave holds many groups and visits them in turn), which is why few samples per "
+                   "pixel scale badly; the gather time is this run's "
                    "resolve + all-gather of one band (a single rank unless --gpus > 1), so the prediction leaves out what eight "
                    "ranks on xGMI add"}
     for spp in sorted({args.spp, 8 * args.spp}):
@@ -396,7 +403,7 @@ def main():
         if os.path.exists(tfile):
             try:
                 t = json.load(open(tfile))
-                if t.get("library_sha256") == library_digest() and t.get("schedule") == args.schedule:
+                if t.get("library_sha256") == library_digest() and t.get("schedule") == args.schedule and t.get("arithmetic", "strict") == args.arith:
                     traffic = t["kernels"].get(kernel)
             except Exception:
                 traffic = None

@@ -50,7 +50,7 @@ int main(int argc, char **argv)
 {
     int device = 0, frames = 4, steps = 32;  // repeat_count = 32, main.cpp:515
     size_t width = 1024, height = 1024, rays = 0;
-    uint32_t warp = 64, spp = 0, band_first = 0, band_rows = 0, flags = RT_FLAG_FREE_SCHEDULE;
+    uint32_t warp = 64, spp = 0, band_first = 0, band_rows = 0, flags = RT_FLAG_FREE_SCHEDULE | RT_FLAG_ARITH_MAD;  // (-cl-mad-enable, main.cpp:253)
     bool force_rccl = false;
     std::vector<int> devices;
     std::string models = "assets/bun_zipper.ply;assets/bun_zipper.ply", out = "frame.ppm";

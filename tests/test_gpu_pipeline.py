@@ -394,7 +394,7 @@ def test_cpp_host_renders_the_same_frame(tmp_path, bunny_scene_128):
     assert os.path.exists(exe), "run `make host` (or __graft_entry__.build())"
     out = str(tmp_path / "frame.ppm")
     run = subprocess.run([exe, "--width", "128", "--height", "128", "--rays", "16384", "--frames", "1", "--steps", "32",
-                          "--warp", "32", "--schedule", "reference", "--models", S.BUNNY + ";" + S.BUNNY, "--out", out],
+                          "--warp", "32", "--schedule", "reference", "--arith", "strict", "--models", S.BUNNY + ";" + S.BUNNY, "--out", out],
                          cwd=root, capture_output=True, text=True, timeout=240)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "Frame ready in" in run.stdout

@@ -7,14 +7,21 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 schedule = sys.argv[2] if len(sys.argv) > 2 else "free"   # which bench.py --schedule the counters were collected on
+arith = sys.argv[3] if len(sys.argv) > 3 else "mad"       # ... and which --arith
 src = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc_summary.json")))
 report, traffic = {}, {}
 for name, c in sorted(src.items()):
     if "rtd::k_" not in name:
         continue
     k = name.split("::")[-1]
-    if k.endswith("<true>" if schedule == "reference" else "<false>"):
-        continue  # the other schedule's instance of a kernel (not launched in this run, or only by set-up calls)
+    if "<" in k:
+        # template arguments: <schedule is free, multiply-adds fused> for the visiting kernels, <fused> for the others;
+        # the other instances of a kernel were not launched in this run, or only by set-up calls
+        targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        if len(targs) == 2 and targs != [str(schedule == "free").lower(), str(arith == "mad").lower()]:
+            continue
+        if len(targs) == 1 and targs[0] in ("true", "false") and targs[0] != str(arith == "mad").lower():
+            continue
     k = k.split("<")[0]
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte read requests as 64 bytes,
     # so the read side is doubled (calibrated for wide streaming reads; other widths are uncalibrated).
@@ -49,8 +56,11 @@ for name, c in sorted(src.items()):
 json.dump(report, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
 import hashlib
 lib = os.path.join(ROOT, "raytracer_amd", "csrc", "librt_hip.so")
-stamp = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "schedule": schedule,
-         "unit": "HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies a 128-byte read request as 64 bytes)",
+stamp = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "schedule": schedule, "arithmetic": arith,
+         "unit": "HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies a 128-byte read request as 64 bytes; calibrated on "
+                 "wide streaming reads, so the scattered 64-byte requests of these kernels may be counted up to twice: the read side lies "
+                 "between kernels_read_once and this figure)",
+         "kernels_fetch_counted_once": {k: r["hbm_read_bytes"] / 2 + r["hbm_write_bytes"] for k, r in report.items()},
          "kernels": traffic}
 json.dump(stamp, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for k, r in report.items():
