@@ -288,11 +288,24 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            torch.cuda.set_device(device)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group("gloo")
+        # RCCL announces itself on stdout when its communicator is created (at the first collective); stdout is for the one
+        # JSON line, so until then it is pointed at stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                torch.cuda.set_device(device)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+                warm = torch.zeros(1, device="cuda")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group("gloo")
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     tensor_device = "cuda" if args.backend == "nccl" else "cpu"
 
     if args.serial:

@@ -23,6 +23,15 @@
 
 #define ORC_TRACE_ONLY 1u
 
+/* The two scan loops are also compiled for CPUs with a fused multiply-add instruction, so that fmaf() is one
+ * instruction there instead of a library call; which clone runs is chosen when the library is loaded.  The
+ * arithmetic is the same either way: contraction stays off (-ffp-contract=off), fmaf() is exact by definition. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define HOT_LOOP __attribute__((target_clones("fma", "default")))
+#else
+#define HOT_LOOP
+#endif
+
 typedef struct { float x, y, z; } v3;
 
 struct orc_ctx {
@@ -291,7 +300,7 @@ static void transform(uint32_t group_id, const rt_ray_queue *ray, local_ray *res
 /* shader.cl:76-101 */
 /* With mad, (corner - start) * inv_dir is evaluated as fma(corner, inv_dir, -(start * inv_dir)): the second
  * product once per ray, one fused operation per corner coordinate. */
-static uint32_t aabb_shader(const local_ray *ray, const rt_aabb_shader *shader, const rt_ray_hit *cur, rt_ray_hit *hit,
+HOT_LOOP static uint32_t aabb_shader(const local_ray *ray, const rt_aabb_shader *shader, const rt_ray_hit *cur, rt_ray_hit *hit,
                             const rt_aabb *aabb, int mad)
 {
     aabb += shader->aabb_offs;
@@ -321,7 +330,7 @@ static uint32_t aabb_shader(const local_ray *ray, const rt_aabb_shader *shader, 
 }
 
 /* shader.cl:115-139.  Returns material id or 0xFFFFFFFF; norm_pos = (object-space normal, t). */
-static uint32_t mesh_shader(const local_ray *ray, const rt_mesh_shader *shader, float norm_pos[4], const rt_vertex *vtx,
+HOT_LOOP static uint32_t mesh_shader(const local_ray *ray, const rt_mesh_shader *shader, float norm_pos[4], const rt_vertex *vtx,
                             const uint32_t *tri, uint32_t *hit_tri, int mad)
 {
     vtx += shader->vtx_offs;

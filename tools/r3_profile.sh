@@ -13,7 +13,7 @@ timeout -k 10 200 python3 bench.py $B --width 3840 --height 2160 --shading diffu
 timeout -k 10 200 python3 bench.py $B --scene dragon --grid 5 --shading diffuse > $o/x_grid5.json
 timeout -k 10 200 python3 bench.py $B --gpus 1 --collective > $o/x_collective.json
 for f in r3_bench x_strict x_reference x_driver x_serial x_4k_diffuse x_grid5 x_collective; do python3 -c "
-import json; d=json.load(open('$o/$f.json')); print('$f', round(d['value'],1), round(d['ms_per_step'],4), d['roofline'].get('frac'), d['roofline'].get('traffic'), d['stage_ms_per_step'])"; done
+import json; d=json.loads([l for l in open('$o/$f.json') if l.startswith('{')][-1]); print('$f', round(d['value'],1), round(d['ms_per_step'],4), d['roofline'].get('frac'), d['roofline'].get('traffic'), d['stage_ms_per_step'])"; done
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof -o r3 -- python3 -u /root/repo/bench.py $B > $o/prof_bench.json 2> $o/prof.err
 find $o/prof -name "*kernel_stats.csv" -exec cp {} $o/r3_kernel_stats.csv \;
