@@ -1281,9 +1281,9 @@ __device__ __forceinline__ bool visit_aabb(uint32_t g, RaySlot *ray, const Proce
 // (run_end_group) and carries the parked entries over, so no shading launch is needed.
 // PLACE: one byte per candidate's place in its list, or two for scenes with lists of more than 256 boxes
 // (24 instead of 20 KB of LDS per workgroup for the columns, i.e. six instead of seven workgroups per CU).
-template <bool FREE, bool MAD, typename PLACE>
-__device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spill_list, float (*s_pos)[kAabbThreads],
-                                             PLACE (*s_idx)[kAabbThreads], uint32_t head_lds, uint32_t first_index, uint32_t tid)
+template <bool FREE, bool MAD, typename PLACE, int THREADS = kAabbThreads>
+__device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spill_list, float (*s_pos)[THREADS],
+                                             PLACE (*s_idx)[THREADS], uint32_t head_lds, uint32_t first_index, uint32_t tid)
 {
     const uint32_t index = first_index + tid;
     DevGlobal *glob = a.frame.glob;
@@ -1333,7 +1333,7 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
         // The samples that start here all enter the camera's root: a visit of its own, with the ray worked out in
         // registers and no pending entries.  A ray that comes out of an instance list at a model's root goes on below.
         uint32_t group_flags = 0;
-        done = visit_aabb<kAabbCap, kAabbThreads, false, true, MAD, true, PLACE>(uniform_value(key), ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid,
+        done = visit_aabb<kAabbCap, THREADS, false, true, MAD, true, PLACE>(uniform_value(key), ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid,
                                                                      new_key, group_flags, sample);
         visit = done && (group_flags & RT_F_LOCAL0) && ((new_key >> RT_GROUP_SH_SHIFT) & RT_GROUP_SH_MASK) == RT_SH_AABB;
         asm volatile("" ::: "memory");  // the next visit reads what this one has stored to the slot
@@ -1346,7 +1346,7 @@ __device__ __forceinline__ void process_aabb(const ProcessArgs &a, uint32_t *spi
             if (key != __builtin_amdgcn_readfirstlane(key)) continue;
             todo = false;
             const uint32_t g = uniform_value(key);  // every lane still here holds the same key
-            done = visit_aabb<kAabbCap, kAabbThreads, false, FREE, MAD, false, PLACE>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key,
+            done = visit_aabb<kAabbCap, THREADS, false, FREE, MAD, false, PLACE>(g, ray, a, s_pos, s_idx, nullptr, nullptr, 0, tid, new_key,
                                                                                   group_flags, 0, head_lds);
         }
         // Free schedule: a ray that has just been through a list of instances (the scene root) and whose
