@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 
 #include "scene.h"
@@ -47,14 +48,18 @@ rth_scene *rth_scene_build(const rth_scene_spec *in, char *err, size_t err_len)
     spec.band_rows = in->band_rows;
     spec.grid = in->grid;
 
-    rth_scene *out = new rth_scene;
-    std::string message;
-    if (!rt::build_scene(spec, out->scene, message)) {
+    // No exception crosses the C boundary: an allocation that fails is a failed build with a message.
+    rth_scene *out = nullptr;
+    try {
+        out = new rth_scene;
+        std::string message;
+        if (rt::build_scene(spec, out->scene, message)) return out;
         set_error(err, err_len, message);
-        delete out;
-        return nullptr;
+    } catch (const std::exception &e) {
+        set_error(err, err_len, std::string("scene build: ") + e.what());
     }
-    return out;
+    delete out;
+    return nullptr;
 }
 
 void rth_scene_free(rth_scene *scene)

@@ -14,6 +14,9 @@ extern "C" {
 
 typedef struct rth_scene rth_scene;
 
+/* A zero in n_obj, the thresholds, width, height or ray_count selects the reference's own value (256 instances,
+ * thresholds of 128, 1024 x 1024 pixels, 1,048,576 ray slots: main.cpp:270-272, 510, 516); band_rows 0 = the whole
+ * image; grid k > 0 = k*k*k instances on a lattice instead of the random field of n_obj. */
 typedef struct {
     const char *model_files; /* ';'-separated list of ASCII PLY paths */
     uint32_t n_obj, tri_threshold, aabb_threshold;

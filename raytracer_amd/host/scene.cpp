@@ -69,7 +69,7 @@ bool build_scene(const SceneSpec &spec, Scene &scene, std::string &error)
         return false;
     }
     const uint32_t rows = spec.band_rows ? spec.band_rows : spec.height;
-    if (spec.band_first + rows > spec.height) {
+    if (uint64_t(spec.band_first) + rows > spec.height) {
         error = "band exceeds the image";
         return false;
     }

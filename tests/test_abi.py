@@ -61,3 +61,25 @@ def test_invalid_config_is_rejected_without_touching_a_gpu():
     assert lib.rt_create(C.byref(cfg), C.byref(h)) == 1
     assert lib.rt_step(None, 1) == 1
     assert lib.rt_destroy(None) == 1
+
+
+def test_without_a_gpu_the_product_fails_loudly(bunny_scene_64):
+    """There is no CPU path behind the C ABI: on a machine without a GPU a context cannot be created, the Python
+    mirror raises, and the C++ host exits with an error instead of rendering anything."""
+    import subprocess
+    lib = api.hip_lib()
+    h = C.c_void_p()
+    cfg = api.Config(0, 64, 64, 8192, 0, 0, 0, 0, 0)
+    rc = lib.rt_create(C.byref(cfg), C.byref(h))
+    if rc == 0:
+        lib.rt_destroy(h)
+        pytest.skip("this machine has a GPU")
+    assert lib.rt_status_string(rc) == b"RT_ERR_NO_DEVICE" and not h
+    with pytest.raises(api.RtError, match="RT_ERR_NO_DEVICE"):
+        api.RayTracer(bunny_scene_64)
+    exe = os.path.join(os.path.dirname(api.HIP_LIB_PATH), "..", "host", "rt_main")
+    run = subprocess.run([exe, "--width", "64", "--height", "64", "--frames", "1", "--out", os.devnull],
+                         capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(HEADER)))
+    assert run.returncode == 1 and "RT_ERR_NO_DEVICE" in run.stdout
+    assert subprocess.run([exe, "--spp", "600", "--width", "3840", "--height", "2160"], capture_output=True).returncode == 2
+    assert subprocess.run([exe, "--no-such-flag"], capture_output=True).returncode == 2

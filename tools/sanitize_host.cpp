@@ -1,0 +1,130 @@
+// sanitize_host.cpp -- developer tool: the C++ scene builder (raytracer_amd/host) and the oracle (oracle/rt_oracle.c) under
+// AddressSanitizer, UndefinedBehaviorSanitizer and the leak checker, on the CPU (tools/sanitize_host.sh builds and runs it).
+// It drives the two libraries through their C entry points the way the tests do: scenes with one and two models, a narrow
+// hierarchy, a row band, a grid of instances, an instance list of more than 256 boxes, bad inputs; frames with the
+// reference's shading, mirror and diffuse bounces, either arithmetic, one and several threads, finished at granularity 1;
+// rt_trace_closest's and the single-sample frame's counterparts; the sort and compaction stages on random pairs.
+// GPU code is not covered: the device sanitizers are not available on the GPU boxes.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <string>
+#include <random>
+#include <algorithm>
+#include "host_capi.h"
+#include "rt_oracle.h"
+
+static rth_scene *build(const std::string &files, uint32_t w, uint32_t h, uint32_t pool, uint32_t n_obj = 256, uint32_t tt = 128, uint32_t at = 128,
+                        uint32_t bf = 0, uint32_t br = 0, uint32_t grid = 0)
+{
+    rth_scene_spec s{files.c_str(), n_obj, tt, at, w, h, pool, bf, br, grid};
+    char err[512] = "";
+    rth_scene *sc = rth_scene_build(&s, err, sizeof err);
+    if (!sc) { std::printf("build failed: %s\n", err); }
+    return sc;
+}
+
+static void run_oracle(rth_scene *sc, uint32_t w, uint32_t h, uint32_t pool, uint32_t flags, uint32_t warp, uint32_t limit, int steps, int threads)
+{
+    rt_config cfg{};
+    cfg.width = w; cfg.height = h; cfg.ray_count = pool; cfg.warp_width = warp; cfg.sample_limit = limit; cfg.hit_capacity = limit;
+    cfg.row_offset = rth_scene_row_offset(sc); cfg.flags = flags;
+    orc_ctx *o = orc_create(&cfg);
+    orc_set_threads(o, threads);
+    size_t ng, nm, na, nv, nt;
+    const rt_group *g = rth_scene_groups(sc, &ng);
+    const rt_matrix *m = rth_scene_matrices(sc, &nm);
+    const rt_aabb *a = rth_scene_aabbs(sc, &na);
+    const rt_vertex *v = rth_scene_vertices(sc, &nv);
+    const uint32_t *t = rth_scene_triangles(sc, &nt);
+    int rc = orc_upload_scene(o, rth_scene_global(sc), g, ng, m, nm, a, na, v, nv, t, nt);
+    if (rc) { std::printf("upload rc %d\n", rc); std::exit(1); }
+    orc_init_frame(o);
+    orc_step(o, steps);
+    if (limit) {
+        orc_set_warp_width(o, 1); orc_step(o, 1);
+        for (int i = 0; i < 400 && orc_global(o)->ray_count; i++) orc_step(o, 1);
+    }
+    std::vector<uint8_t> img(size_t(w) * h * 4);
+    orc_resolve_rgba8(o, img.data());
+    rt_counters c; orc_get_counters(o, &c);
+    std::printf("  flags %x warp %u: primary %llu shadow %llu left %u\n", flags, warp, (unsigned long long)c.primary_spawned, (unsigned long long)c.shadow_spawned, orc_global(o)->ray_count);
+    // camera rays + trace closest
+    std::vector<uint32_t> samples(500);
+    for (size_t i = 0; i < samples.size(); i++) samples[i] = uint32_t(i * 7 % (w * h));
+    std::vector<rt_ray> rays(samples.size());
+    std::vector<rt_hit_record> hits(samples.size());
+    orc_camera_rays(o, samples.data(), uint32_t(samples.size()), rays.data());
+    orc_trace_closest(o, rays.data(), uint32_t(rays.size()), hits.data());
+    orc_trace_closest(o, rays.data(), 0, hits.data());
+    orc_init_frame_samples(o, samples.data(), 100);
+    orc_step(o, 50);
+    orc_destroy(o);
+}
+
+int main(int argc, char **argv)
+{
+    const std::string bunny = argv[1];
+    const std::string standin = std::string(argc > 2 ? argv[2] : "/tmp") + "/sanitize_standin.ply";
+    if (rth_write_standin_ply(standin.c_str(), 264, 132)) return 1;
+    {
+        rth_scene *sc = build(bunny + ";" + bunny, 64, 64, 8192);
+        if (!sc) return 1;
+        std::printf("bunny x2\n");
+        run_oracle(sc, 64, 64, 8192, 0, 32, 0, 30, 1);
+        run_oracle(sc, 64, 64, 8192, 2, 32, 4096, 24, 4);
+        run_oracle(sc, 64, 64, 8192, (2u << 8) | (2u << 12) | (0x5EEDu << 16), 7, 4096, 17, 2);
+        run_oracle(sc, 64, 64, 8192, (1u << 8) | (2u << 12) | (0x5EEDu << 16) | 2, 64, 4096, 10, 1);
+        rth_scene_free(sc);
+    }
+    {
+        rth_scene *sc = build(bunny + ";" + standin, 96, 40, 8192, 256, 128, 8, 8, 16);
+        if (!sc) return 1;
+        std::printf("bunny + standin, narrow hierarchy, band\n");
+        run_oracle(sc, 96, 16, 8192, 0, 32, 96 * 16, 24, 3);
+        rth_scene_free(sc);
+    }
+    {
+        rth_scene *sc = build(standin + ";" + standin, 64, 64, 8192, 256, 128, 128, 0, 0, 3);
+        if (!sc) return 1;
+        std::printf("grid 3\n");
+        run_oracle(sc, 64, 64, 8192, (2u << 8) | (2u << 12) | (0x5EEDu << 16), 32, 4096, 24, 2);
+        rth_scene_free(sc);
+    }
+    {
+        rth_scene *sc = build(bunny, 64, 64, 8192, 300);  // more than 256 boxes under the root
+        if (!sc) return 1;
+        std::printf("300 instances\n");
+        run_oracle(sc, 64, 64, 8192, 0, 32, 4096, 24, 1);
+        rth_scene_free(sc);
+    }
+    // bad inputs
+    build("/nonexistent.ply", 64, 64, 8192);
+    rth_scene_free(build(bunny, 0, 64, 8192));
+    // stage entry points
+    std::mt19937 rng(3);
+    for (uint32_t count : {8192u, 24576u}) {
+        for (uint32_t n : {0u, 1u, 777u, 8192u, count}) {
+            for (uint32_t G : {1u, 33u, 2560u, 70000u}) {
+                std::vector<rt_index_pair> in(count), out(count);
+                for (auto &p : in) { p.key = rng() % G | (rng() & 0xFF000000u); p.slot = rng(); }
+                orc_sort_pairs(in.data(), out.data(), count, n, G);
+                if (G >= 8 && n == count) {
+                    std::vector<rt_group_data> gd(G);
+                    for (auto &x : gd) { x.count[1] = 0; x.offset[1] = 0xFFFFFFFFu; x.base[0] = x.base[1] = x.count[0] = x.offset[0] = 0; }
+                    rt_global_data glob{}; glob.group_count = G; glob.ray_count = n;
+                    std::vector<rt_index_pair> packed(count);
+                    for (auto &p : out) p.key = (p.key & 0xFFFFFF) % G;
+                    std::vector<rt_index_pair> sorted = out;
+                    // fully sort by id so that compaction's precondition holds
+                    std::stable_sort(sorted.begin(), sorted.begin() + n, [](const rt_index_pair &a, const rt_index_pair &b) { return a.key < b.key; });
+                    for (size_t i = n; i < count; i++) sorted[i].key = G - 1;
+                    orc_compact_groups(sorted.data(), packed.data(), count, gd.data(), &glob, 32);
+                }
+            }
+        }
+    }
+    std::printf("done\n");
+    return 0;
+}
