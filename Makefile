@@ -19,7 +19,7 @@ HOST_HEADERS := $(wildcard $(HOST)/*.h) include/rt_hip.h
 
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared -ffp-contract=off -fno-fast-math -munsafe-fp-atomics \
             -Wall -Wno-unused-function -Iinclude -I$(CSRC)
-CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -I$(HOST)
+CXXFLAGS := -O2 -std=c++17 -fPIC -pthread -ffp-contract=off -fno-fast-math -Wall -Wextra -Iinclude -I$(HOST)
 
 all: device host oracle
 

@@ -6,6 +6,7 @@
 // mesh.  Build with -ffp-contract=off: every float expression here is evaluated as written.
 
 #include "model.h"
+#include "parallel.h"
 
 #include <sys/stat.h>
 #include <unistd.h>
@@ -359,18 +360,34 @@ void Model::prepare()
 
 // ---------------------------------------------------------------- hierarchy
 
+// The hierarchy is built level by level: the nodes of one level hold disjoint ranges of the triangle order, so
+// their sorts run side by side (parallel_for), each exactly the sort the reference's recursion performs on that
+// range (model.cpp:28-40) -- a node's range is left by its parent's sort in the same order either way.  Which
+// nodes become box groups is then counted from the leaves up (model.cpp:42-46).
 void Model::subdivide(size_t tri_threshold, size_t aabb_threshold)
 {
     assert(nodes_.size() == 1);
-    split(0, tri_threshold, aabb_threshold, true);
+    std::vector<int> level(1, 0), todo;
+    while (!level.empty()) {
+        todo.clear();
+        for (int node : level)
+            if (nodes_[node].count >= tri_threshold && nodes_[node].count >= 2) todo.push_back(node);  // (fewer than two cannot be halved)
+        const size_t first_child = nodes_.size();
+        nodes_.resize(first_child + 2 * todo.size());  // (no thread grows the vector)
+        parallel_for(todo.size(), [&](size_t i) { split_node(todo[i], int(first_child + 2 * i)); });
+        level.clear();
+        for (size_t i = 0; i < 2 * todo.size(); i++) level.push_back(int(first_child + i));
+    }
+    count_boxes(0, aabb_threshold, true);
 }
 
-// Returns how many boxes this subtree contributes to the closest enclosing box group.
-size_t Model::split(int node, size_t tri_threshold, size_t aabb_threshold, bool is_root)
+// Median split of one node along the longest axis of its centroid bounds (model.cpp:28-40).  The triangles are
+// sorted as (centroid coordinate, triangle) pairs: std::sort makes the same comparisons in the same order as on
+// the triangle numbers with an indirect comparison, so it leaves the same permutation -- ties included, which an
+// unstable sort resolves by its own moves -- without a scattered read per comparison.
+void Model::split_node(int node, int first_child)
 {
     const uint32_t first = nodes_[node].first, count = nodes_[node].count;
-    if (count < tri_threshold) return 1;
-
     const Bounds box = nodes_[node].box;
     const Vec3 extent = box.hi - box.lo;
     int axis;
@@ -378,30 +395,38 @@ size_t Model::split(int node, size_t tri_threshold, size_t aabb_threshold, bool 
     else if (extent.y > extent.z) axis = 1;
     else axis = 2;
 
+    struct Keyed {
+        float key;
+        uint32_t face;
+    };
     uint32_t *begin = order_.data() + first;
-    const Face *faces = faces_.data();
-    std::sort(begin, begin + count, [faces, axis](uint32_t a, uint32_t b) { return faces[a].center[axis] < faces[b].center[axis]; });
+    std::vector<Keyed> keyed(count);
+    for (uint32_t i = 0; i < count; i++) keyed[i] = Keyed{faces_[begin[i]].center[axis], begin[i]};
+    std::sort(keyed.begin(), keyed.end(), [](const Keyed &a, const Keyed &b) { return a.key < b.key; });
+    for (uint32_t i = 0; i < count; i++) begin[i] = keyed[i].face;
 
     const uint32_t half = count / 2;
     Node lower, upper;
     lower.first = first;
     lower.count = half;
     lower.box = box;
-    lower.box.hi[axis] = faces_[begin[half - 1]].center[axis];
+    lower.box.hi[axis] = keyed[half - 1].key;
     upper.first = first + half;
     upper.count = count - half;
     upper.box = box;
-    upper.box.lo[axis] = faces_[begin[half]].center[axis];
+    upper.box.lo[axis] = keyed[half].key;
+    nodes_[first_child] = lower;
+    nodes_[first_child + 1] = upper;
+    nodes_[node].child[0] = first_child;
+    nodes_[node].child[1] = first_child + 1;
+}
 
-    const int lower_id = int(nodes_.size());
-    nodes_.push_back(lower);
-    const int upper_id = int(nodes_.size());
-    nodes_.push_back(upper);
-    nodes_[node].child[0] = lower_id;
-    nodes_[node].child[1] = upper_id;
-
-    const size_t below = split(lower_id, tri_threshold, aabb_threshold, false) +
-                         split(upper_id, tri_threshold, aabb_threshold, false);
+// Returns how many boxes this subtree contributes to the closest enclosing box group: a node with at least
+// aabb_threshold leaves below it (or the root) becomes a group of its own and counts as one (model.cpp:42-46).
+size_t Model::count_boxes(int node, size_t aabb_threshold, bool is_root)
+{
+    if (nodes_[node].child[0] < 0) return 1;
+    const size_t below = count_boxes(nodes_[node].child[0], aabb_threshold, false) + count_boxes(nodes_[node].child[1], aabb_threshold, false);
     if (!is_root && below < aabb_threshold) return below;
     nodes_[node].aabb_count = uint32_t(below);
     return 1;

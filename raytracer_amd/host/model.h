@@ -108,7 +108,8 @@ private:
     };
 
     void prepare();
-    size_t split(int node, size_t tri_threshold, size_t aabb_threshold, bool is_root);
+    void split_node(int node, int first_child);
+    size_t count_boxes(int node, size_t aabb_threshold, bool is_root);
     void reserve_node(int node, ResourceManager &mngr);
     uint32_t fill_node(int node, ResourceManager &mngr, uint32_t material_id, uint32_t *aabb_cursor);
 

@@ -5,6 +5,7 @@
 // resolution, a row band per GPU, an optional regular grid of instances).
 
 #include "scene.h"
+#include "parallel.h"
 
 #include <chrono>
 #include <cmath>
@@ -123,11 +124,9 @@ bool build_scene(const SceneSpec &spec, Scene &scene, std::string &error)
 
     for (size_t k = 0; k < models.size(); k++) models[k]->fill(mngr, k & 1 ? red_id : green_id);
     scene.resident_triangles = 0;
-    for (uint32_t i = 0; i < n_obj; i++) {
-        const Model &model = *models[i % models.size()];
-        model.put(instance_box[i], mat[i], i);
-        scene.resident_triangles += model.triangle_count();
-    }
+    for (uint32_t i = 0; i < n_obj; i++) scene.resident_triangles += models[i % models.size()]->triangle_count();
+    // every instance's world-space box comes from all of its model's vertices (model.cpp:216-222): one item each
+    parallel_for(n_obj, [&](size_t i) { models[i % models.size()]->put(instance_box[i], mat[i], uint32_t(i)); });
     if (!mngr.full()) {
         error = "internal: reserved and emitted sizes differ";
         return false;

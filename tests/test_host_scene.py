@@ -132,3 +132,16 @@ def test_mesh_cache_gives_the_same_scene(tmp_path, monkeypatch):
     damaged = S.build_scene([S.BUNNY], 64, 64, 8192, n_obj=4)
     assert damaged.models_from_cache == 0
     assert os.path.getsize(files[0]) == len(raw)
+
+
+def test_scene_does_not_depend_on_the_number_of_build_threads(standin_ply, monkeypatch):
+    """The hierarchy build sorts the nodes of a level side by side and works out the instance boxes side by side
+    (RT_HOST_THREADS, default: the machine's threads, at most 16); every emitted byte is the one-thread build's."""
+    names = ("groups", "aabbs", "vertices", "triangles", "matrices", "data")
+    built = []
+    for threads in ("1", "2", "7"):
+        monkeypatch.setenv("RT_HOST_THREADS", threads)
+        built.append(S.build_scene([S.BUNNY, standin_ply], 96, 64, 8192, aabb_threshold=16))
+    for sc in built[1:]:
+        for n in names:
+            assert np.ascontiguousarray(getattr(sc, n)).tobytes() == np.ascontiguousarray(getattr(built[0], n)).tobytes(), n
