@@ -8,6 +8,9 @@ scene_bunny_digests.json  digests of the scene arrays emitted by the REFERENCE's
 sort_cases.npz            inputs and outputs of the ray-key sort from the oracle
 pipeline_bunny128.npz     state after 40 steps of the reference pipeline on the 128x128 bunny scene
 drain_bunny64.npz         a finished 2-samples-per-pixel frame (accumulator, image, hit records)
+pipeline_bunny128_mad.npz, drain_bunny64_mad.npz, drain_bunny64_mirror2_mad.npz
+                          the same kinds of vector in the fused arithmetic (RT_FLAG_ARITH_MAD): state after 48 steps, a
+                          finished 1-sample-per-pixel frame with the reference's shading and with two mirror bounces
 
 The oracle is a restatement of the reference kernels (parity unpinned, see oracle/rt_oracle.h); these
 files pin the oracle against regressions and give the GPU tests vectors that do not need the oracle.
@@ -85,6 +88,37 @@ def main():
                         counters=np.array([o.counters()], L.counters_dtype))
     print("drained after", steps, "steps;", o.counters())
     o.close()
+
+    # 5. the same two kinds of vector in the fused arithmetic (RT_FLAG_ARITH_MAD), with the parameters of the GPU tests
+    #    that compare the HIP path with the oracle of that mode (tests/test_arith_modes.py)
+    sc = S.build_scene([S.BUNNY, S.BUNNY], 128, 128, 16384)
+    o = O.Oracle(sc, warp_width=32, hit_capacity=16384 * 8, mad=True)
+    o.init_frame()
+    o.step(48)
+    rl = o.ray_list
+    np.savez_compressed(os.path.join(HERE, "pipeline_bunny128_mad.npz"),
+                        steps=np.uint32(48), warp_width=np.uint32(32),
+                        global_data=o.global_data.copy(), ray_index=o.ray_index.copy(), grp_data=o.grp_data.copy(),
+                        area=o.area.copy(), hits=o.hits.copy(), counters=np.array([o.counters()], L.counters_dtype),
+                        ray_field_sha=np.array([[name, sha(rl[name])] for name in L.ray_queue_dtype.names]))
+    o.close()
+    sc = S.build_scene([S.BUNNY, S.BUNNY], 64, 64, 8192)
+    limit = 64 * 64
+    for name, shading in (("drain_bunny64_mad.npz", 0), ("drain_bunny64_mirror2_mad.npz", 1 << 8 | 2 << 12 | 0x5EED << 16)):
+        o = O.Oracle(sc, warp_width=32, sample_limit=limit, hit_capacity=limit, shading=shading, mad=True)
+        o.init_frame()
+        o.step(24)
+        o.set_warp_width(1)
+        o.step(1)
+        steps = 25
+        while int(o.global_data["ray_count"][0]):
+            o.step(1)
+            steps += 1
+        np.savez_compressed(os.path.join(HERE, name), steps=np.uint32(steps), sample_limit=np.uint32(limit), shading=np.uint32(shading),
+                            area=o.area.copy(), image=o.resolve_rgba8(), hits=o.hits.copy(),
+                            counters=np.array([o.counters()], L.counters_dtype))
+        print(name, "drained after", steps, "steps;", o.counters())
+        o.close()
 
 
 if __name__ == "__main__":

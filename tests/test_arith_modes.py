@@ -4,6 +4,8 @@ business, so no output of the reference pins them.  Here the fused places are st
 oracle and the HIP path agree bit for bit within either mode, and across the modes a frame differs only where
 a ray grazes an edge: hit ids equal on at least 99.99 % of camera rays, t within 1e-5 relative, image within
 1 LSB on all but a handful of pixels.  Parity unpinned, like the kernels themselves."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,8 @@ from raytracer_amd import api, layout as L, scene as S
 
 import helpers as H
 from test_oracle_pipeline import camera_rays, run_to_completion as oracle_to_completion
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def same_hits_fraction(a, b):
@@ -44,6 +48,67 @@ def test_oracle_mad_frame_is_schedule_independent(bunny_scene_64):
         o.close()
     assert H.same_bytes(results[0][0], results[1][0])
     assert np.allclose(results[0][1], results[1][1], rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_mad_golden_vectors(bunny_scene_128, bunny_scene_64):
+    """The fused mode frozen in committed vectors: state after 48 steps, a finished frame with the reference's shading
+    and one with two mirror bounces (tests/golden/make_golden.py)."""
+    import hashlib
+    from oracle import pyoracle as O
+    g = np.load(os.path.join(GOLDEN, "pipeline_bunny128_mad.npz"))
+    o = O.Oracle(bunny_scene_128, warp_width=int(g["warp_width"]), hit_capacity=len(g["hits"]), mad=True)
+    o.init_frame()
+    o.step(int(g["steps"]))
+    assert H.same_bytes(o.global_data, g["global_data"]) and H.same_bytes(o.ray_index, g["ray_index"])
+    assert H.same_bytes(o.grp_data, g["grp_data"]) and H.same_bytes(o.area, g["area"]) and H.same_bytes(o.hits, g["hits"])
+    assert H.same_bytes(np.array([o.counters()], L.counters_dtype), g["counters"])
+    rl = o.ray_list
+    for name, digest in g["ray_field_sha"]:
+        assert hashlib.sha256(np.ascontiguousarray(rl[str(name)]).tobytes()).hexdigest() == str(digest), name
+    o.close()
+    strict = np.load(os.path.join(GOLDEN, "pipeline_bunny128.npz"))
+    assert not H.same_bytes(g["hits"][:len(strict["hits"])], strict["hits"])      # the modes do round differently
+    for name in ("drain_bunny64_mad.npz", "drain_bunny64_mirror2_mad.npz"):
+        g = np.load(os.path.join(GOLDEN, name))
+        limit = int(g["sample_limit"])
+        o = O.Oracle(bunny_scene_64, warp_width=32, sample_limit=limit, hit_capacity=limit, shading=int(g["shading"]), mad=True)
+        assert oracle_to_completion(o, max_steps=1500) == int(g["steps"]), name
+        assert H.same_bytes(o.area, g["area"]) and H.same_bytes(o.hits, g["hits"]), name
+        assert H.same_bytes(o.resolve_rgba8(), g["image"]), name
+        assert H.same_bytes(np.array([o.counters()], L.counters_dtype), g["counters"]), name
+        o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_mad_golden_vectors(bunny_scene_128, bunny_scene_64):
+    """The HIP path in the fused mode against the committed vectors alone (no oracle in the loop): state after 48
+    steps of the reference schedule; finished frames on both schedules."""
+    import hashlib
+    from test_gpu_pipeline import run_to_completion
+    g = np.load(os.path.join(GOLDEN, "pipeline_bunny128_mad.npz"))
+    rt = api.RayTracer(bunny_scene_128, warp_width=int(g["warp_width"]), hit_capacity=len(g["hits"]), mad=True)
+    rt.init_frame()
+    rt.make_step(int(g["steps"]))
+    rays, index, groups = rt.dump_state()
+    assert H.same_bytes(rt.global_data(), g["global_data"])
+    assert H.same_bytes(index, g["ray_index"]) and H.same_bytes(groups, g["grp_data"])
+    assert H.same_bytes(rt.hits(), g["hits"])
+    assert np.allclose(rt.area(), g["area"], rtol=1e-5, atol=1e-6)
+    for name, digest in g["ray_field_sha"]:
+        assert hashlib.sha256(np.ascontiguousarray(rays[str(name)]).tobytes()).hexdigest() == str(digest), name
+    rt.close()
+    for name in ("drain_bunny64_mad.npz", "drain_bunny64_mirror2_mad.npz"):
+        g = np.load(os.path.join(GOLDEN, name))
+        limit = int(g["sample_limit"])
+        for free in (True, False):
+            rt = api.RayTracer(bunny_scene_64, warp_width=64, sample_limit=limit, hit_capacity=limit, free_schedule=free,
+                               shading=int(g["shading"]), mad=True)
+            run_to_completion(rt, steps_parked=12, max_steps=1500)
+            assert H.same_bytes(rt.hits(), g["hits"]), (name, free)
+            assert np.allclose(rt.area(), g["area"], rtol=1e-5, atol=1e-6), (name, free)
+            assert np.abs(rt.draw_frame().astype(int) - g["image"].astype(int)).max() <= 1, (name, free)
+            assert int(rt.counters()["shadow_spawned"]) == int(g["counters"][0]["shadow_spawned"]), (name, free)
+            rt.close()
 
 
 @pytest.mark.gpu
