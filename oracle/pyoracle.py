@@ -53,6 +53,7 @@ def lib():
         o.orc_pool_size.argtypes = [vp]
         o.orc_get_counters.argtypes = [vp, vp]
         o.orc_get_work.argtypes = [vp, vp]
+        o.orc_get_hit_histogram.argtypes = [vp, vp]
         o.orc_trace_closest.restype = C.c_int
         o.orc_trace_closest.argtypes = [vp, vp, u32, vp]
         o.orc_camera_rays.argtypes = [vp, vp, u32, vp]
@@ -160,6 +161,12 @@ class Oracle:
         out = np.zeros(1, work_dtype)
         lib().orc_get_work(self.h, out.ctypes.data)
         return out[0]
+
+    def hit_histogram(self):
+        """Box-group visits by number of accepted boxes, bins 0..64 and "more than 64" (single-threaded runs only)."""
+        out = np.zeros(L.MAX_HITS + 2, np.uint64)
+        lib().orc_get_hit_histogram(self.h, out.ctypes.data)
+        return out
 
     def resolve_rgba8(self):
         out = np.zeros((self.scene.height, self.scene.width, 4), np.uint8)
