@@ -94,9 +94,15 @@ public:
         return word(w) && w == literal;
     }
 
-    void rest_of_line()
+    // The text of the comment line as the reference's template takes it ("comment %*[^\n] ", model.cpp:148): white
+    // space of any kind first, line ends included, then at least one character, up to the end of that line.  (After
+    // a bare "comment" the NEXT line is taken for the text, and the file then fails to load there as it does here.)
+    bool comment_text()
     {
+        skip_space();
+        if (!*at_) return false;
         while (*at_ && *at_ != '\n') at_++;
+        return true;
     }
 
     bool number(float &out)
@@ -159,7 +165,7 @@ bool slurp(const char *file, std::vector<char> &text)
 // exactly what its counts say, is ignored.  The directory is only used when it belongs to this user and nobody
 // else may write to it (a directory another local user created under /tmp could hold planted files).
 struct CacheHeader {
-    char magic[8];  // "RTMESH2": version of this layout and of the parser that filled it
+    char magic[8];  // "RTMESH3": version of this layout and of the parser that filled it
     uint64_t hash, file_size, n_vtx, n_tri;
 };
 
@@ -203,7 +209,7 @@ bool read_cache(const std::string &path, uint64_t hash, uint64_t file_size, std:
     CacheHeader h;
     struct stat st;
     bool ok = ::fstat(fileno(in), &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() &&
-              std::fread(&h, sizeof(h), 1, in) == 1 && !std::memcmp(h.magic, "RTMESH2", 8) && h.hash == hash &&
+              std::fread(&h, sizeof(h), 1, in) == 1 && !std::memcmp(h.magic, "RTMESH3", 8) && h.hash == hash &&
               h.file_size == file_size && h.n_vtx && h.n_tri && h.n_vtx < (1ull << 32) && h.n_tri < (1ull << 32);
     // the counts must account for the file's size exactly before anything is sized by them
     ok = ok && uint64_t(st.st_size) == sizeof(h) + h.n_vtx * sizeof(Vec3) + h.n_tri * sizeof(faces[0]);
@@ -229,7 +235,7 @@ void write_cache(const std::string &path, uint64_t hash, uint64_t file_size, con
     FILE *out = std::fopen(tmp.c_str(), "wb");
     if (!out) return;
     CacheHeader h;
-    std::memcpy(h.magic, "RTMESH2", 8);
+    std::memcpy(h.magic, "RTMESH3", 8);
     h.hash = hash;
     h.file_size = file_size;
     h.n_vtx = positions.size();
@@ -275,8 +281,7 @@ bool Model::load_file(const char *file)
     // Header, in the fixed order the reference's scanf templates demand (model.cpp:145-160).
     size_t n_vtx = 0, n_tri = 0;
     if (!tok.expect("ply") || !tok.expect("format") || !tok.expect("ascii") || !tok.expect("1.0")) return false;
-    if (!tok.expect("comment")) return false;
-    tok.rest_of_line();
+    if (!tok.expect("comment") || !tok.comment_text()) return false;
     if (!tok.expect("element") || !tok.expect("vertex") || !tok.number(n_vtx) || !n_vtx) return false;
     for (const char *axis : {"x", "y", "z"})
         if (!tok.expect("property") || !tok.expect("float") || !tok.expect(axis)) return false;
