@@ -145,3 +145,20 @@ def test_scene_does_not_depend_on_the_number_of_build_threads(standin_ply, monke
     for sc in built[1:]:
         for n in names:
             assert np.ascontiguousarray(getattr(sc, n)).tobytes() == np.ascontiguousarray(getattr(built[0], n)).tobytes(), n
+
+
+@pytest.mark.skipif(O.ref_model_lib() is None, reason="oracle/_ref/libref_model.so not built")
+@pytest.mark.parametrize("tri_threshold,aabb_threshold", [(128, 8), (128, 16), (64, 16), (256, 256), (16, 2), (1000, 128)])
+def test_other_hierarchy_shapes_match_the_reference_builder(standin_ply, tri_threshold, aabb_threshold):
+    """The builder's two thresholds (main.cpp:270 passes 128 and 128) with other values -- the narrow hierarchies the
+    benchmark's extras run among them -- against the reference's own subdivide/reserve/fill with the same values."""
+    files = [S.BUNNY, standin_ply]
+    sc = S.build_scene(files, 64, 64, 8192, n_obj=6, tri_threshold=tri_threshold, aabb_threshold=aabb_threshold)
+    groups, aabbs, vertices, triangles = O.ref_model_build(files, sc.matrices, tri_threshold, aabb_threshold)
+    assert len(groups) == len(sc.groups) and np.array_equal(triangles, sc.triangles)
+    assert aabbs.tobytes() == sc.aabbs.tobytes()
+    assert np.array_equal(vertices["pos"][:, :3].view(np.uint32), sc.vertices["pos"][:, :3].view(np.uint32))
+    assert np.array_equal(vertices["norm"][:, :3].view(np.uint32), sc.vertices["norm"][:, :3].view(np.uint32))
+    for gid in list(aabbs["group_id"]) + [int(sc.data["cam"]["root_group"][0])]:
+        idx, kind = int(gid) & L.GROUP_ID_MASK, (int(gid) >> 28) & 0xF
+        assert np.array_equal(groups["w"][idx][:3 if kind == L.SH_AABB else 4], sc.groups["w"][idx][:3 if kind == L.SH_AABB else 4]), idx
