@@ -246,6 +246,13 @@ def ref_model_lib():
     return _ref
 
 
+def ref_layout():
+    """Sizes, member offsets and constants of the reference's ray-tracer.h as the reference build sees them."""
+    r = ref_model_lib()
+    r.refm_layout.restype = C.c_char_p
+    return {k: int(v) for k, v in (item.split("=") for item in r.refm_layout().decode().split(";") if item)}
+
+
 def ref_model_build(files, matrices, tri_threshold=128, aabb_threshold=128):
     """Runs the reference's Model/ResourceManager classes; returns (groups, aabbs, vertices, triangles)."""
     r = ref_model_lib()

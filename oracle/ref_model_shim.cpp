@@ -9,6 +9,8 @@
 
 #include "model.h"  // the reference's header, found through -I/root/reference
 
+#include <cstddef>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -83,6 +85,45 @@ void refm_set_camera(Camera *cam, size_t width, size_t height, float tan_fov, co
 {
     set_camera(*cam, width, height, tan_fov, Vector(pos[0], pos[1], pos[2]), Vector(view[0], view[1], view[2]),
                Vector(up[0], up[1], up[2]));
+}
+
+// Sizes, member offsets and constants of the reference's shared data layout (ray-tracer.h, compiled as C++ with the
+// image's CL headers: cl_float3 is a 16-byte type), as "name=value;" pairs, for pinning include/rt_hip.h.
+const char *refm_layout()
+{
+    static char text[4096];
+    int at = 0;
+#define PUT(name, value) at += std::snprintf(text + at, sizeof(text) - at, "%s=%zu;", name, size_t(value))
+#define SIZE(T) PUT("sizeof " #T, sizeof(T))
+#define OFFS(T, m) PUT(#T "." #m, offsetof(T, m))
+    SIZE(MatShader); SIZE(AABB); SIZE(AABBShader); SIZE(Vertex); SIZE(MeshShader); SIZE(Matrix); SIZE(Group);
+    SIZE(Camera); SIZE(GlobalData); SIZE(GroupData); SIZE(Ray); SIZE(RayHit); SIZE(RayQueue);
+    OFFS(AABB, min); OFFS(AABB, max); OFFS(AABB, group_id); OFFS(AABB, local_id);
+    OFFS(AABBShader, aabb_offs); OFFS(AABBShader, aabb_count); OFFS(AABBShader, flags);
+    OFFS(Vertex, pos); OFFS(Vertex, norm);
+    OFFS(MeshShader, vtx_offs); OFFS(MeshShader, tri_offs); OFFS(MeshShader, tri_count); OFFS(MeshShader, material_id);
+    OFFS(Matrix, x); OFFS(Matrix, y); OFFS(Matrix, z);
+    OFFS(Camera, eye); OFFS(Camera, top_left); OFFS(Camera, dx); OFFS(Camera, dy); OFFS(Camera, width); OFFS(Camera, height);
+    OFFS(Camera, root_group); OFFS(Camera, root_local);
+    OFFS(GlobalData, pixel_offset); OFFS(GlobalData, pixel_count); OFFS(GlobalData, group_count); OFFS(GlobalData, old_count);
+    OFFS(GlobalData, ray_count); OFFS(GlobalData, cam);
+    OFFS(GroupData, base); OFFS(GroupData, count); OFFS(GroupData, offset);
+    OFFS(Ray, start_min); OFFS(Ray, min); OFFS(Ray, dir_max); OFFS(Ray, max);
+    OFFS(RayHit, pos); OFFS(RayHit, group_id); OFFS(RayHit, local_id);
+    OFFS(RayQueue, weight); OFFS(RayQueue, pixel); OFFS(RayQueue, type); OFFS(RayQueue, material_id); OFFS(RayQueue, queue_len);
+    OFFS(RayQueue, ray); OFFS(RayQueue, norm); OFFS(RayQueue, root); OFFS(RayQueue, orig); OFFS(RayQueue, queue);
+    PUT("GROUP_ID_MASK", GROUP_ID_MASK); PUT("GROUP_TR_SHIFT", GROUP_TR_SHIFT); PUT("GROUP_TR_MASK", GROUP_TR_MASK);
+    PUT("GROUP_SH_SHIFT", GROUP_SH_SHIFT); PUT("GROUP_SH_MASK", GROUP_SH_MASK);
+    PUT("tr_none", tr_none); PUT("tr_identity", tr_identity); PUT("tr_ortho", tr_ortho); PUT("tr_affine", tr_affine);
+    PUT("sh_spawn", sh_spawn); PUT("sh_sky", sh_sky); PUT("sh_light", sh_light); PUT("sh_material", sh_material);
+    PUT("sh_aabb", sh_aabb); PUT("sh_mesh", sh_mesh);
+    PUT("spawn_group", spawn_group); PUT("sky_group", sky_group); PUT("light_group", light_group);
+    PUT("f_local0", f_local0); PUT("f_local1", f_local1); PUT("rt_primary", rt_primary); PUT("rt_shadow", rt_shadow);
+    PUT("MAX_HITS", MAX_HITS); PUT("MAX_QUEUE_LEN", MAX_QUEUE_LEN); PUT("RADIX_SHIFT", RADIX_SHIFT);
+#undef OFFS
+#undef SIZE
+#undef PUT
+    return text;
 }
 
 }  // extern "C"

@@ -83,3 +83,79 @@ def test_without_a_gpu_the_product_fails_loudly(bunny_scene_64):
     assert run.returncode == 1 and "RT_ERR_NO_DEVICE" in run.stdout
     assert subprocess.run([exe, "--spp", "600", "--width", "3840", "--height", "2160"], capture_output=True).returncode == 2
     assert subprocess.run([exe, "--no-such-flag"], capture_output=True).returncode == 2
+
+
+PROBE = r"""
+#include <stddef.h>
+#include <stdio.h>
+#include "rt_hip.h"
+#define SIZE(name, T) printf("sizeof %s=%zu;", name, sizeof(T))
+#define OFFS(name, T, m) printf("%s=%zu;", name, offsetof(T, m))
+#define PUT(name, v) printf("%s=%zu;", name, (size_t)(v))
+int main(void)
+{
+    SIZE("MatShader", rt_mat_shader); SIZE("AABB", rt_aabb); SIZE("AABBShader", rt_aabb_shader); SIZE("Vertex", rt_vertex);
+    SIZE("MeshShader", rt_mesh_shader); SIZE("Matrix", rt_matrix); SIZE("Group", rt_group); SIZE("Camera", rt_camera);
+    SIZE("GlobalData", rt_global_data); SIZE("GroupData", rt_group_data); SIZE("Ray", rt_ray); SIZE("RayHit", rt_ray_hit);
+    SIZE("RayQueue", rt_ray_queue);
+    OFFS("AABB.min", rt_aabb, min); OFFS("AABB.max", rt_aabb, max); OFFS("AABB.group_id", rt_aabb, group_id); OFFS("AABB.local_id", rt_aabb, local_id);
+    OFFS("AABBShader.aabb_offs", rt_aabb_shader, aabb_offs); OFFS("AABBShader.aabb_count", rt_aabb_shader, aabb_count); OFFS("AABBShader.flags", rt_aabb_shader, flags);
+    OFFS("Vertex.pos", rt_vertex, pos); OFFS("Vertex.norm", rt_vertex, norm);
+    OFFS("MeshShader.vtx_offs", rt_mesh_shader, vtx_offs); OFFS("MeshShader.tri_offs", rt_mesh_shader, tri_offs);
+    OFFS("MeshShader.tri_count", rt_mesh_shader, tri_count); OFFS("MeshShader.material_id", rt_mesh_shader, material_id);
+    OFFS("Matrix.x", rt_matrix, x); OFFS("Matrix.y", rt_matrix, y); OFFS("Matrix.z", rt_matrix, z);
+    OFFS("Camera.eye", rt_camera, eye); OFFS("Camera.top_left", rt_camera, top_left); OFFS("Camera.dx", rt_camera, dx); OFFS("Camera.dy", rt_camera, dy);
+    OFFS("Camera.width", rt_camera, width); OFFS("Camera.height", rt_camera, height); OFFS("Camera.root_group", rt_camera, root_group);
+    OFFS("Camera.root_local", rt_camera, root_local);
+    OFFS("GlobalData.pixel_offset", rt_global_data, pixel_offset); OFFS("GlobalData.pixel_count", rt_global_data, pixel_count);
+    OFFS("GlobalData.group_count", rt_global_data, group_count); OFFS("GlobalData.old_count", rt_global_data, old_count);
+    OFFS("GlobalData.ray_count", rt_global_data, ray_count); OFFS("GlobalData.cam", rt_global_data, cam);
+    OFFS("GroupData.base", rt_group_data, base); OFFS("GroupData.count", rt_group_data, count); OFFS("GroupData.offset", rt_group_data, offset);
+    OFFS("Ray.start_min", rt_ray, start_min); PUT("Ray.min", offsetof(rt_ray, start_min) + 12); OFFS("Ray.dir_max", rt_ray, dir_max);
+    PUT("Ray.max", offsetof(rt_ray, dir_max) + 12);
+    OFFS("RayHit.pos", rt_ray_hit, pos); OFFS("RayHit.group_id", rt_ray_hit, group_id); OFFS("RayHit.local_id", rt_ray_hit, local_id);
+    OFFS("RayQueue.weight", rt_ray_queue, weight); OFFS("RayQueue.pixel", rt_ray_queue, pixel); OFFS("RayQueue.type", rt_ray_queue, type);
+    OFFS("RayQueue.material_id", rt_ray_queue, material_id); OFFS("RayQueue.queue_len", rt_ray_queue, queue_len);
+    OFFS("RayQueue.ray", rt_ray_queue, start_min); OFFS("RayQueue.norm", rt_ray_queue, norm); OFFS("RayQueue.root", rt_ray_queue, root);
+    OFFS("RayQueue.orig", rt_ray_queue, orig); OFFS("RayQueue.queue", rt_ray_queue, queue);
+    PUT("GROUP_ID_MASK", RT_GROUP_ID_MASK); PUT("GROUP_TR_SHIFT", RT_GROUP_TR_SHIFT); PUT("GROUP_TR_MASK", RT_GROUP_TR_MASK);
+    PUT("GROUP_SH_SHIFT", RT_GROUP_SH_SHIFT); PUT("GROUP_SH_MASK", RT_GROUP_SH_MASK);
+    PUT("tr_none", RT_TR_NONE); PUT("tr_identity", RT_TR_IDENTITY); PUT("tr_ortho", RT_TR_ORTHO); PUT("tr_affine", RT_TR_AFFINE);
+    PUT("sh_spawn", RT_SH_SPAWN); PUT("sh_sky", RT_SH_SKY); PUT("sh_light", RT_SH_LIGHT); PUT("sh_material", RT_SH_MATERIAL);
+    PUT("sh_aabb", RT_SH_AABB); PUT("sh_mesh", RT_SH_MESH);
+    PUT("spawn_group", RT_SPAWN_GROUP); PUT("sky_group", RT_SKY_GROUP); PUT("light_group", RT_LIGHT_GROUP);
+    PUT("f_local0", RT_F_LOCAL0); PUT("f_local1", RT_F_LOCAL1); PUT("rt_primary", RT_RAY_PRIMARY); PUT("rt_shadow", RT_RAY_SHADOW);
+    PUT("MAX_HITS", RT_MAX_HITS); PUT("MAX_QUEUE_LEN", RT_MAX_QUEUE_LEN);
+    return 0;
+}
+"""
+
+
+def test_header_layout_equals_the_reference_headers(tmp_path):
+    """include/rt_hip.h, compiled as C, against the reference's ray-tracer.h as the reference's own build sees it
+    (oracle/_ref, g++ with the image's CL headers): every structure size, member offset and constant."""
+    import subprocess
+    from oracle import pyoracle as O
+    if O.ref_model_lib() is None:
+        pytest.skip("oracle/_ref/libref_model.so not built (needs /root/reference)")
+    want = O.ref_layout()
+    src, exe = tmp_path / "probe.c", tmp_path / "probe"
+    src.write_text(PROBE)
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = {k: int(v) for k, v in (item.split("=") for item in out.split(";") if item)}
+    missing = sorted(set(want) - set(got) - {"RADIX_SHIFT"})       # (the sort's digit width is the kernels' own business)
+    assert not missing, missing
+    assert {k: got[k] for k in got} == {k: want[k] for k in got}
+    # and the numpy views the tests use
+    assert L.ray_queue_dtype.itemsize == want["sizeof RayQueue"] and L.global_dtype.itemsize == want["sizeof GlobalData"]
+    for name, dtype, fields in (("RayQueue", L.ray_queue_dtype, {"weight": "weight", "pixel": "pixel", "type": "type", "material_id": "material_id",
+                                                                  "queue_len": "queue_len", "ray": "start_min", "norm": "norm", "root": "root",
+                                                                  "orig": "orig", "queue": "queue"}),
+                                ("GlobalData", L.global_dtype, {k: k for k in ("pixel_offset", "pixel_count", "group_count", "old_count", "ray_count", "cam")}),
+                                ("Camera", L.camera_dtype, {k: k for k in ("eye", "top_left", "dx", "dy", "width", "height", "root_group", "root_local")}),
+                                ("AABB", L.aabb_dtype, {k: k for k in ("min", "max", "group_id", "local_id")}),
+                                ("GroupData", L.group_data_dtype, {k: k for k in ("base", "count", "offset")}),
+                                ("RayHit", L.ray_hit_dtype, {k: k for k in ("pos", "group_id", "local_id")})):
+        for ref_field, mine in fields.items():
+            assert dtype.fields[mine][1] == want[f"{name}.{ref_field}"], (name, ref_field)
