@@ -162,3 +162,50 @@ def test_other_hierarchy_shapes_match_the_reference_builder(standin_ply, tri_thr
     for gid in list(aabbs["group_id"]) + [int(sc.data["cam"]["root_group"][0])]:
         idx, kind = int(gid) & L.GROUP_ID_MASK, (int(gid) >> 28) & 0xF
         assert np.array_equal(groups["w"][idx][:3 if kind == L.SH_AABB else 4], sc.groups["w"][idx][:3 if kind == L.SH_AABB else 4]), idx
+
+
+def glibc_random(seed, n):
+    """The first n values of glibc's random() after srandom(seed) (its default generator: additive feedback over 31
+    words, x[i] = x[i-3] + x[i-31], seeded by a Lehmer generator, 310 values discarded), written out independently."""
+    r = [0] * (344 + n)
+    r[0] = seed
+    for i in range(1, 31):
+        r[i] = (16807 * r[i - 1]) % 2147483647
+    for i in range(31, 34):
+        r[i] = r[i - 31]
+    for i in range(34, 344 + n):
+        r[i] = (r[i - 31] + r[i - 3]) & 0xFFFFFFFF
+    return [x >> 1 for x in r[344:]]
+
+
+def test_the_reference_scene_literally():
+    """create_buffers() of the reference (main.cpp:268-343) at its own size: 256 instances from glibc's unseeded
+    random(), instance i of model i & 1 with local id i, the two materials, the six leading groups, the camera."""
+    sc = S.build_scene([S.BUNNY, S.BUNNY], 1024, 1024, 1 << 20)
+    rnd = glibc_random(1, 4 * 256)
+    assert rnd[:4] == [1804289383, 846930886, 1681692777, 1714636915]
+    f = np.float32
+    for i in range(256):
+        a, tx, ty, tz = rnd[4 * i:4 * i + 4]
+        alpha = 2 * 3.14159265359 * a / 2147483647
+        m = sc.matrices[i]
+        assert tuple(m["x"]) == (f(np.cos(alpha)), f(0), f(-f(np.sin(alpha))), f(4.0 * tx / 2147483647 - 2)), i
+        assert tuple(m["y"]) == (f(np.sin(alpha)), f(0), f(np.cos(alpha)), f(4.0 * ty / 2147483647)), i
+        assert tuple(m["z"]) == (f(0), f(1), f(0), f(2.0 * tz / 2147483647 - 1)), i
+    cam = sc.data["cam"][0]
+    assert tuple(cam["eye"][:3]) == (f(0), f(-0.3), f(0)) and tuple(cam["top_left"][:3]) == (f(-0.5), f(1), f(-0.5))
+    assert tuple(cam["dx"][:3]) == (f(1.0 / 1024), f(0), f(0)) and tuple(cam["dy"][:3]) == (f(0), f(0), f(1.0 / 1024))
+    root_id = 5 | L.TR_IDENTITY << 24 | L.SH_AABB << 28
+    assert (int(cam["width"]), int(cam["height"]), int(cam["root_group"]), int(cam["root_local"])) == (1024, 1024, root_id, 0)
+    assert int(sc.data["ray_count"][0]) == 1 << 20 and sc.group_count == 2560         # align(6 + 2 * 1033 + 1, 512)
+    colours = sc.groups["w"][3:5].view(np.float32)
+    assert colours.tolist() == [[f(0.2), f(0.9), f(0.2), f(0.1)], [f(0.9), f(0.2), f(0.2), f(0.1)]]   # green, red (main.cpp:319-323)
+    assert tuple(sc.groups["w"][5][:3]) == (0, 256, 1)                                 # the scene root: boxes 0..255, f_local0
+    boxes = sc.aabbs[:256]
+    assert np.array_equal(boxes["local_id"], np.arange(256))
+    roots = boxes["group_id"]
+    assert len(set(roots[0::2])) == 1 and len(set(roots[1::2])) == 1 and roots[0] != roots[1]   # (i & 1 ? dragon : bunny)
+    for r in (int(roots[0]), int(roots[1])):
+        assert (r >> 24) & 0xF == L.TR_ORTHO and r >> 28 == L.SH_AABB
+    leaf_material = {int(sc.groups["w"][int(g) & L.GROUP_ID_MASK][3]) for g in sc.aabbs["group_id"] if int(g) >> 28 == L.SH_MESH}
+    assert leaf_material == {3 | L.SH_MATERIAL << 28, 4 | L.SH_MATERIAL << 28}         # tr_none | sh_material
