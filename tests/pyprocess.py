@@ -3,24 +3,81 @@ float32, written from the reference's text (ray-tracer.cl:10-16, 39-74, 90-232; 
 oracle/rt_oracle.c -- so that the C oracle can be checked against something other than itself
 (tests/test_oracle_second_opinion.py).  Slow (Python per ray, numpy per box list and per leaf): for samples of rays.
 
-Floating point as the build defines it where OpenCL leaves it open: every operation rounded to float on its own (no
-fused multiply-add: the strict mode), dot(a, b) = (ax*bx + ay*by) + az*bz, normalize(v) = v * (1 / sqrt(dot(v, v))),
-pow(x, 5) = (x^2 * x^2) * x and pow(x, 100) = (x^64 * x^32) * x^4 by repeated squaring.  The accumulator `area` is not
-modelled; where the reference leaves a value indeterminate (queue[0].pos of an emptied queue) the old value stays."""
+Floating point as the build defines it where OpenCL leaves it open: dot(a, b) = (ax*bx + ay*by) + az*bz,
+normalize(v) = v * (1 / sqrt(dot(v, v))), pow(x, 5) = (x^2 * x^2) * x and pow(x, 100) = (x^64 * x^32) * x^4 by repeated
+squaring; in the strict mode every operation is rounded to float on its own.  With MAD set (set_mode) the multiply-adds
+are fused at the places include/rt_hip.h lists for RT_FLAG_ARITH_MAD, restated from that list: three-term sums of
+products (transform, normal interpolation and rotation, every dot product) as fma(c, w, fma(b, v, a*u)); a cross
+product's component as fma(p, q, -(r*s)); start + dir*t and the camera ray as chains of fma; the slab test's
+(corner - start) * inv_dir as fma(corner, inv_dir, -(start * inv_dir)).  fma() here is exact: the product and sum are
+formed as fractions and rounded to float once.  The accumulator `area` is not modelled; where the reference leaves a
+value indeterminate (queue[0].pos of an emptied queue) the old value stays."""
+from fractions import Fraction
+
 import numpy as np
 
 from raytracer_amd import layout as L
 
 f32 = np.float32
 INF = f32(np.inf)
+MAD = False
+
+
+def set_mode(mad):
+    global MAD
+    MAD = bool(mad)
+
+
+def fma(a, b, c):
+    """a * b + c rounded to float once."""
+    a, b, c = float(a), float(b), float(c)
+    if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
+        with np.errstate(invalid="ignore", over="ignore"):
+            return f32(np.float64(a) * np.float64(b) + np.float64(c))
+    exact = Fraction(a) * Fraction(b) + Fraction(c)
+    if exact == 0:
+        return f32(a * b + c)                       # (the sign of a zero result: as the unfused sum gives it)
+    with np.errstate(over="ignore"):
+        near = f32(float(exact))                    # rounded to double, then to float: right unless a tie got in between
+        if not np.isfinite(near):
+            return near
+        towards = f32(np.nextafter(near, INF if exact > Fraction(float(near)) else -INF))
+    if Fraction(float(near)) == exact or not np.isfinite(towards):
+        return near
+    d_near, d_other = abs(exact - Fraction(float(near))), abs(Fraction(float(towards)) - exact)
+    if d_other < d_near or (d_other == d_near and (int(towards.view(np.uint32)) & 1) == 0):
+        return towards
+    return near
+
+
+def sum3(a, u, b, v, c, w):
+    """a*u + b*v + c*w, left to right; fused: fma(c, w, fma(b, v, a*u))."""
+    if MAD:
+        return fma(c, w, fma(b, v, f32(a * u)))
+    return f32(f32(f32(a * u) + f32(b * v)) + f32(c * w))
+
+
+def lin3(a, u, b, v, c, w):
+    return np.array([sum3(a[k], u, b[k], v, c[k], w) for k in range(3)], f32)
+
+
+def madd(a, s, b):
+    """a * s + b per component (a chain link of the fused mode)."""
+    if MAD:
+        return np.array([fma(a[k], s, b[k]) for k in range(3)], f32)
+    return ((a * s).astype(f32) + b).astype(f32)
 
 
 def dot(a, b):
-    return f32(f32(f32(a[0] * b[0]) + f32(a[1] * b[1])) + f32(a[2] * b[2]))
+    return sum3(a[0], b[0], a[1], b[1], a[2], b[2])
 
 
 def cross(a, b):
-    return np.array([f32(a[1] * b[2]) - f32(a[2] * b[1]), f32(a[2] * b[0]) - f32(a[0] * b[2]), f32(a[0] * b[1]) - f32(a[1] * b[0])], f32)
+    def comp(p, q, r, s_):
+        if MAD:
+            return fma(p, q, f32(-f32(r * s_)))
+        return f32(f32(p * q) - f32(r * s_))
+    return np.array([comp(a[1], b[2], a[2], b[1]), comp(a[2], b[0], a[0], b[2]), comp(a[0], b[1], a[1], b[0])], f32)
 
 
 def normalize(v):
@@ -60,7 +117,10 @@ def init_ray(cam, ray, sample, row_offset=0):
     ray["weight"] = 1
     ray["type"] = 0
     ray["start_min"][:3] = cam["eye"][:3]
-    v = ((cam["top_left"][:3] + x * cam["dx"][:3]).astype(f32) + (y * cam["dy"][:3]).astype(f32)).astype(f32)
+    if MAD:
+        v = madd(cam["dy"][:3], y, madd(cam["dx"][:3], x, cam["top_left"][:3]))
+    else:
+        v = ((cam["top_left"][:3] + x * cam["dx"][:3]).astype(f32) + (y * cam["dy"][:3]).astype(f32)).astype(f32)
     ray["dir_max"][:3] = normalize(v)
     ray["root"]["group_id"] = cam["root_group"]
     ray["root"]["local_id"] = (cam["root_local"], 0)
@@ -90,7 +150,7 @@ def mat_shader(ray, color):
     ray["weight"][:3] = (ray["weight"][:3] * c).astype(f32)
     ray["weight"][3] = f32(ray["weight"][3] * f32(1))
     ray["type"] = 1
-    ray["start_min"][:3] = (ray["start_min"][:3] + (ray["dir_max"][3] * d).astype(f32)).astype(f32)
+    ray["start_min"][:3] = madd(d, f32(ray["dir_max"][3]), ray["start_min"][:3].copy())
     ray["dir_max"][:3] = light
     root = ray["root"]
     return reset_ray(ray, int(root["group_id"]), (int(root["local_id"][0]), int(root["local_id"][1])), L.LIGHT_GROUP)
@@ -105,9 +165,9 @@ def transform(key, ray, matrices):
         mx, my, mz = m["x"], m["y"], m["z"]
         cols = [np.array([mx[k], my[k], mz[k]], f32) for k in range(3)]
         rel = (start - np.array([mx[3], my[3], mz[3]], f32)).astype(f32)
-        start = (((mx[:3] * rel[0]).astype(f32) + (my[:3] * rel[1]).astype(f32)).astype(f32) + (mz[:3] * rel[2]).astype(f32)).astype(f32)
+        start = lin3(mx[:3], rel[0], my[:3], rel[1], mz[:3], rel[2])
         d0 = d.copy()
-        d = (((mx[:3] * d0[0]).astype(f32) + (my[:3] * d0[1]).astype(f32)).astype(f32) + (mz[:3] * d0[2]).astype(f32)).astype(f32)
+        d = lin3(mx[:3], d0[0], my[:3], d0[1], mz[:3], d0[2])
     return start, d, cols
 
 
@@ -138,8 +198,13 @@ def aabb_shader(start, d, ray_min, ray_max, shader, cur_local, aabbs):
     boxes = aabbs[first:first + count]
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         inv = (f32(1) / d).astype(f32)
-        pos1 = ((boxes["min"] - start).astype(f32) * inv).astype(f32)
-        pos2 = ((boxes["max"] - start).astype(f32) * inv).astype(f32)
+        if MAD:
+            neg = (-(start * inv).astype(f32)).astype(f32)     # -(start * inv_dir), once per ray
+            pos1 = np.array([[fma(b[k], inv[k], neg[k]) for k in range(3)] for b in boxes["min"]], f32).reshape(-1, 3)
+            pos2 = np.array([[fma(b[k], inv[k], neg[k]) for k in range(3)] for b in boxes["max"]], f32).reshape(-1, 3)
+        else:
+            pos1 = ((boxes["min"] - start).astype(f32) * inv).astype(f32)
+            pos2 = ((boxes["max"] - start).astype(f32) * inv).astype(f32)
     hits = []
     for i in range(count):
         # min/max as OpenCL's fmin/fmax: a NaN operand gives the other one
@@ -181,7 +246,7 @@ def mesh_shader(start, d, ray_min, ray_max, shader, vertices, triangles):
     i, u, v = hit
     n0, n1, n2 = (vertices["norm"][idx[i, k], :3].astype(f32) for k in range(3))
     a = f32(f32(f32(1) - u) - v)
-    normal = (((n0 * a).astype(f32) + (n1 * u).astype(f32)).astype(f32) + (n2 * v).astype(f32)).astype(f32)
+    normal = lin3(n0, a, n1, u, n2, v)
     return material_id, normal, best, i
 
 
@@ -243,7 +308,7 @@ def process(ray, key, position, scene, pixel_offset, row_offset=0):
             if int(ray["type"]) == 1:
                 material_id = L.SPAWN_GROUP          # (area[pixel].w += weight.w is not modelled)
             else:
-                ray["norm"][:3] = (((cols[0] * normal[0]).astype(f32) + (cols[1] * normal[1]).astype(f32)).astype(f32) + (cols[2] * normal[2]).astype(f32)).astype(f32)
+                ray["norm"][:3] = lin3(cols[0], normal[0], cols[1], normal[1], cols[2], normal[2])
                 ray["dir_max"][3] = t
                 ray["orig"]["pos"] = t
                 ray["orig"]["group_id"] = old[0][1]

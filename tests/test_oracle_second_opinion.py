@@ -1,7 +1,7 @@
 """The C oracle against a second statement of `process` written independently from the reference's text
 (tests/pyprocess.py, numpy float32, one ray at a time): at several points of a run a sample of slots of every kind
 (starting samples, sky, light, material, box groups, leaves) is advanced one step by both, and every field of the
-slot and its new sort key must agree bit for bit.  Strict arithmetic; no GPU."""
+slot and its new sort key must agree bit for bit.  Both arithmetic modes; no GPU."""
 import numpy as np
 import pytest
 
@@ -42,11 +42,13 @@ def advance_and_compare(o, sc, per_kind, rng, seen):
                 assert got["dir_max"][3] == got["orig"]["pos"] and int(got["orig"]["group_id"]) == key
 
 
+@pytest.mark.parametrize("mad", [False, True])
 @pytest.mark.parametrize("files,warp", [("bunny", 4), ("bunny+standin", 8)])
-def test_process_step_by_step_against_the_second_statement(standin_ply, files, warp):
+def test_process_step_by_step_against_the_second_statement(standin_ply, files, warp, mad):
     models = [S.BUNNY, S.BUNNY] if files == "bunny" else [S.BUNNY, standin_ply]
     sc = S.build_scene(models, 64, 64, 8192)
-    o = O.Oracle(sc, warp_width=warp)
+    P.set_mode(mad)
+    o = O.Oracle(sc, warp_width=warp, mad=mad)
     o.init_frame()
     # init_rays: every slot against init_ray of the second statement (ray-tracer.cl:56-82)
     rays = o.ray_list
