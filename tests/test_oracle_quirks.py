@@ -142,3 +142,22 @@ def test_a_shadowed_sample_can_darken_its_pixel_more_than_once(bunny_scene_64):
     lit = hit & (w < 1.5) & (o.area[:, :3].sum(axis=1) > 0)
     assert lit.sum() > 100                                          # most hit samples see the light
     o.close()
+
+
+def test_resolve_against_numpy(bunny_scene_64):
+    """update_image (ray-tracer.cl:305-309): rgba = pow(area / (area.w + 1e-6), 1 / 2.2), stored as UNORM8 the way
+    write_imagef converts (clamp, times 255, round to nearest even).  numpy's float32 power may differ from libm's powf
+    in the last place, hence one step of tolerance; pixels nothing has been added to resolve to zero."""
+    limit = 64 * 64
+    o = O.Oracle(bunny_scene_64, warp_width=32, sample_limit=limit)
+    run_to_completion(o)
+    area = o.area.copy()
+    image = o.resolve_rgba8().reshape(-1, 4)
+    o.close()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        v = np.power((area / (area[:, 3:4] + np.float32(1e-6))).astype(np.float32), np.float32(1 / 2.2))
+    want = np.rint(np.clip(np.nan_to_num(v, nan=0.0), 0, 1) * np.float32(255)).astype(int)
+    assert np.abs(image.astype(int) - want).max() <= 1
+    assert (image[:, 3] >= 254).all()                                # alpha: w / (w + 1e-6) is one to within rounding
+    empty = np.zeros((4, 4), np.float32)
+    assert np.array_equal(np.rint(np.power(empty / (empty[:, 3:4] + np.float32(1e-6)), np.float32(1 / 2.2)) * 255), np.zeros((4, 4)))
