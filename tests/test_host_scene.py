@@ -136,9 +136,12 @@ def test_mesh_cache_gives_the_same_scene(tmp_path, monkeypatch):
 
 def test_scene_does_not_depend_on_the_number_of_build_threads(standin_ply, monkeypatch):
     """The hierarchy build sorts the nodes of a level side by side and works out the instance boxes side by side
-    (RT_HOST_THREADS, default: the machine's threads, at most 16); every emitted byte is the one-thread build's."""
+    (RT_HOST_THREADS, default: the machine's threads, at most 16), and a PLY file's vertex and face lines are parsed side by
+    side; every emitted byte is the one-thread build's."""
     names = ("groups", "aabbs", "vertices", "triangles", "matrices", "data")
     built = []
+    monkeypatch.setenv("RT_MESH_CACHE", "")              # parse the text: with more than one thread line by line, side by side
+    monkeypatch.setenv("RT_PLY_PARALLEL_MIN", "0")       # (files this small would otherwise go through the tokenizer)
     for threads in ("1", "2", "7"):
         monkeypatch.setenv("RT_HOST_THREADS", threads)
         built.append(S.build_scene([S.BUNNY, standin_ply], 96, 64, 8192, aabb_threshold=16))

@@ -83,9 +83,23 @@ VARIANTS = {
 }
 
 
+def _reflow(text, per_line):
+    """The same tokens with `per_line` of them on every data line: no longer one element per line."""
+    head, body = text.split("end_header\n")
+    tokens = body.split()
+    lines = [" ".join(tokens[i:i + per_line]) for i in range(0, len(tokens), per_line)]
+    return head + "end_header\n" + "\n".join(lines) + "\n"
+
+
+
+@pytest.mark.parametrize("parser", ["tokenizer", "lines"])
 @pytest.mark.parametrize("name", sorted(VARIANTS))
-def test_loader_agrees_with_the_reference(tmp_path, monkeypatch, name):
+def test_loader_agrees_with_the_reference(tmp_path, monkeypatch, name, parser):
+    """parser: the tokenizer alone (one thread), or the line-by-line parser of large files first (forced here on a small
+    one), which hands anything that is not one element per line back to the tokenizer."""
     monkeypatch.setenv("RT_MESH_CACHE", "")          # the text parser, not the binary cache
+    monkeypatch.setenv("RT_HOST_THREADS", "1" if parser == "tokenizer" else "4")
+    monkeypatch.setenv("RT_PLY_PARALLEL_MIN", "0")
     path = str(tmp_path / "mesh.ply")
     with open(path, "w", newline="") as f:
         f.write(ply_text(POS, FACES, **VARIANTS[name]))
@@ -109,3 +123,18 @@ def test_out_of_range_index_is_refused_by_both(tmp_path, monkeypatch):
     faces[5] = (0, -1, 2)
     open(path, "w").write(ply_text(POS, faces))
     assert both_loaders(path) == (None, None)
+
+
+@pytest.mark.parametrize("per_line", [1, 5, 7])
+def test_elements_need_not_sit_on_lines_of_their_own(tmp_path, monkeypatch, per_line):
+    """The reference reads a stream of tokens (fscanf), wherever the line ends fall: so does the loader, also when the
+    line-by-line parser of large files gets the file first."""
+    monkeypatch.setenv("RT_MESH_CACHE", "")
+    monkeypatch.setenv("RT_HOST_THREADS", "4")
+    monkeypatch.setenv("RT_PLY_PARALLEL_MIN", "0")
+    path = str(tmp_path / "mesh.ply")
+    open(path, "w").write(_reflow(ply_text(POS, FACES), per_line))
+    mine, ref = both_loaders(path)
+    assert mine is not None and ref is not None
+    assert mine[0].tobytes() == ref[0].tobytes() and np.array_equal(mine[2], ref[2])
+    assert np.array_equal(mine[1]["pos"][:, :3].view(np.uint32), ref[1]["pos"][:, :3].view(np.uint32))

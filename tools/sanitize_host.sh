@@ -32,4 +32,4 @@ int main(int, char **argv)
 CPP
 g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -fPIC -shared -ffp-contract=off -Iinclude -Iraytracer_amd/host raytracer_amd/host/model.cpp raytracer_amd/host/scene.cpp raytracer_amd/host/host_capi.cpp -o $out/librt_host_tsan.so
 g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -Iinclude -Iraytracer_amd/host $out/tsan_build.cpp -o $out/tsan_build $out/librt_host_tsan.so -Wl,-rpath,$out
-RT_MESH_CACHE=$out/cache RT_HOST_THREADS=8 $out/tsan_build assets/bun_zipper.ply $out/sanitize_standin.ply
+RT_MESH_CACHE= RT_PLY_PARALLEL_MIN=0 RT_HOST_THREADS=8 $out/tsan_build assets/bun_zipper.ply $out/sanitize_standin.ply   # (cache off: the files are parsed line by line on several threads)
