@@ -56,7 +56,7 @@ struct orc_ctx {
     rt_hit_record *hits;
     rt_counters counters;
     orc_work work;
-    uint64_t hit_hist[RT_MAX_HITS + 2]; /* visits by number of accepted boxes; last bin: more than 64 */
+    uint64_t hit_hist[RT_MAX_HITS + 2]; /* visits by the number of boxes aabb_shader returned (a node given up for more than 64 returns 0); last bin unused */
 };
 
 /* ------------------------------------------------------------------ vector helpers */
@@ -742,7 +742,9 @@ static void k_set_ray_index(const rt_global_data *data, const rt_group_data *grp
         index -= (index < data->old_count ? grp.base[0] : grp.base[1]);
         if (index < grp.count[1]) index += grp.offset[1];
         else index += grp.offset[0] - grp.count[1];
-        dst_index[index] = src;
+        /* (the reference stores unconditionally, ray-tracer.cl:301; the bound only matters for group data that does not
+         * belong to the index given -- caller data of the stage entry point -- and keeps such a call from writing wild) */
+        if (index < count) dst_index[index] = src;
     }
 }
 

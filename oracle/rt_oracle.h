@@ -63,7 +63,8 @@ rt_hit_record *orc_hits(orc_ctx *ctx);
 uint32_t orc_pool_size(orc_ctx *ctx);
 void orc_get_counters(orc_ctx *ctx, rt_counters *dst);
 void orc_get_work(orc_ctx *ctx, orc_work *dst);
-/* Visits of box groups by number of accepted boxes, RT_MAX_HITS + 2 bins (single-threaded runs only). */
+/* Visits of box groups by the number of boxes aabb_shader returned, RT_MAX_HITS + 2 bins (single-threaded runs only); a
+ * node given up because it accepted more than RT_MAX_HITS boxes returns 0 and is counted there. */
 void orc_get_hit_histogram(orc_ctx *ctx, uint64_t *dst);
 
 /* Loads caller rays as primary samples 0..n-1 (replacing init_rays) and steps with granularity 1
