@@ -82,10 +82,11 @@ class Scene:
 
 
 def _copy(ptr, count, dtype):
+    """An owned numpy array of `count` records copied from the library's memory (one copy, no intermediate bytes object)."""
     if not count:
         return np.zeros(0, dtype)
-    raw = C.string_at(ptr, count * dtype.itemsize)
-    return np.frombuffer(raw, dtype=dtype, count=count).copy()
+    view = (C.c_char * (count * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(view, dtype=dtype, count=count).copy()
 
 
 def build_scene(models, width=1024, height=1024, ray_count=1024 * 1024, n_obj=256, tri_threshold=128,
