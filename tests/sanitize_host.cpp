@@ -1,5 +1,5 @@
-// sanitize_host.cpp -- developer tool: the C++ scene builder (raytracer_amd/host) and the oracle (oracle/rt_oracle.c) under
-// AddressSanitizer, UndefinedBehaviorSanitizer and the leak checker, on the CPU (tools/sanitize_host.sh builds and runs it).
+// sanitize_host.cpp -- not a pytest test: the C++ scene builder (raytracer_amd/host) and the oracle (oracle/rt_oracle.c) under
+// AddressSanitizer, UndefinedBehaviorSanitizer and the leak checker, on the CPU (tests/sanitize_host.sh builds and runs it).
 // It drives the two libraries through their C entry points the way the tests do: scenes with one and two models, a narrow
 // hierarchy, a row band, a grid of instances, an instance list of more than 256 boxes, bad inputs; frames with the
 // reference's shading, mirror and diffuse bounces, either arithmetic, one and several threads, finished at granularity 1;
