@@ -155,3 +155,18 @@ def test_sort_hits_network(n):
             offs //= 2
         base *= 2
     assert [x[1] for x in a] == got["group_id"].tolist()
+
+
+@pytest.mark.parametrize("group_count", [1, 2, 32, 33, 1024, 1025, 1 << 24])
+def test_sort_at_the_ends_of_the_key_range(group_count):
+    """One group (the pass loop of main.cpp:444-445 runs no pass at all), group counts either side of a digit boundary
+    (32 | 33: one or two 5-bit passes; 1,024 | 1,025: two or three), and the largest id the 24 id bits hold."""
+    rng = np.random.default_rng(group_count)
+    pairs = H.random_pairs(rng, 16384, group_count)
+    if group_count == 1 << 24:
+        pairs["key"][:64] = (pairs["key"][:64] & np.uint32(0xFF000000)) | np.uint32((1 << 24) - 1)   # the top id is there
+    for n in (16384, 8193):
+        got = O.sort_pairs(pairs, n, group_count)
+        assert H.same_bytes(got, H.expected_sort(pairs, n, group_count)), n
+    if group_count == 1:
+        assert H.same_bytes(O.sort_pairs(pairs, 16384, 1), pairs)        # nothing moves
