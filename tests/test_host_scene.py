@@ -212,3 +212,10 @@ def test_the_reference_scene_literally():
         assert (r >> 24) & 0xF == L.TR_ORTHO and r >> 28 == L.SH_AABB
     leaf_material = {int(sc.groups["w"][int(g) & L.GROUP_ID_MASK][3]) for g in sc.aabbs["group_id"] if int(g) >> 28 == L.SH_MESH}
     assert leaf_material == {3 | L.SH_MATERIAL << 28, 4 | L.SH_MATERIAL << 28}         # tr_none | sh_material
+
+
+def test_leaf_with_too_many_vertices_is_an_error_not_a_crash():
+    """A leaf's triangles index its vertices with ten bits (shader.cl:125, model.cpp:122); the reference asserts that a
+    leaf touches fewer than 1,024 (model.cpp:66).  Here a threshold that allows larger leaves fails the build cleanly."""
+    with pytest.raises(RuntimeError, match="more than 1023 vertices"):
+        S.build_scene([S.BUNNY], 64, 64, 8192, n_obj=2, tri_threshold=8192)
