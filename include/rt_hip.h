@@ -146,7 +146,13 @@ typedef struct {
  * camera ray's top_left + dx*x + dy*y are chains of fma; and the slab test's (corner - start) * inv_dir
  * (shader.cl:86-87) is fma(corner, inv_dir, -(start*inv_dir)) with the second product taken once per ray.
  * Division, sqrt, pow and all comparisons are the same in both modes.  A sample's hit can differ between the modes
- * where a ray grazes an edge; within a mode every result is reproducible bit for bit. */
+ * where a ray grazes an edge; within a mode every result is reproducible bit for bit.
+ * Limit: the fused slab test needs 1 / dir to be a number on every axis.  For a direction component that is exactly
+ * zero, fma(corner, +-inf, -+inf) is not a number for corners on one side of zero and infinite for those on the other,
+ * whatever the ray's start: boxes beside the ray are entered, boxes around it can be missed, pending queues overflow
+ * and the ray may never finish (rt_trace_closest then gives up with RT_ERR_NOT_READY).  The rays the library makes
+ * itself -- camera, shadow and bounce rays -- have no exactly zero component; axis-parallel rays of a caller belong on
+ * a context without this flag, where (corner - start) * (1 / dir) handles them as the reference does. */
 #define RT_FLAG_ARITH_MAD 2u
 
 /* Shading beyond the reference's one shadow ray per sample, also in rt_config.flags: bits 8-11 say what a

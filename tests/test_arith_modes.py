@@ -221,3 +221,34 @@ def test_gpu_modes_at_the_headline_size(standin_full_ply):
     assert (diff.max(axis=1) > 1).mean() < 1e-4
     mse = (diff[:, :3].astype(np.float64) ** 2).mean()
     assert 10 * np.log10(255.0 ** 2 / max(mse, 1e-12)) > 50
+
+
+def test_fused_mode_does_not_handle_axis_parallel_rays(bunny_scene_64):
+    """A limit of the fused slab test (include/rt_hip.h, tests/test_culling_property.py): a ray with a direction
+    component that is exactly zero.  Forty rays along +y through the centres of instance boxes (a camera with dx = dy = 0
+    and top_left = (0, 1, 0) makes every sample such a ray): in the strict mode all finish and hit a model; in the fused
+    mode the test stops seeing the two axes with an infinite reciprocal, boxes beside the ray are entered, queues
+    overflow and most of the rays are still in flight after 600 steps."""
+    import copy
+    from oracle import pyoracle as O
+    boxes = bunny_scene_64.aabbs[:256]
+    finished = {False: 0, True: 0}
+    hit = {False: 0, True: 0}
+    for k in range(40):
+        centre = 0.5 * (boxes["min"][6 * k] + boxes["max"][6 * k])
+        sc = copy.deepcopy(bunny_scene_64)
+        cam = sc.data["cam"][0]
+        cam["eye"][:3] = (centre[0], -1.0, centre[2])
+        cam["top_left"][:3] = (0, 1, 0)
+        cam["dx"][:] = 0
+        cam["dy"][:] = 0
+        for mad in (False, True):
+            o = O.Oracle(sc, warp_width=1, sample_limit=64 * 64, hit_capacity=1, mad=mad)
+            o.init_frame_samples(np.array([0], np.uint32))
+            assert tuple(o.ray_list[0]["dir_max"][:3]) == (0.0, 1.0, 0.0)
+            o.step(600)
+            finished[mad] += int(o.global_data["ray_count"][0]) == 0
+            hit[mad] += bool(np.isfinite(o.hits["t"][0]))
+            o.close()
+    assert finished[False] == 40 and hit[False] == 40
+    assert finished[True] < 20
