@@ -109,6 +109,7 @@ class RayTracer:
             raise RtError(self.lib.rt_status_string(rc).decode(), detail)
         self.pool = L.align_up(scene.pool_size, L.SORT_TILE)
         self.hit_capacity = hit_capacity
+        self.mad = bool(mad)
         self.upload(scene)
 
     def _check(self, rc):
@@ -202,6 +203,9 @@ class RayTracer:
 
     def trace_closest(self, rays):
         rays = np.ascontiguousarray(rays, dtype=L.ray_dtype)
+        if self.mad and np.any(rays["dir_max"][:, :3] == 0):
+            # the fused slab test needs 1 / dir to be a number on every axis (include/rt_hip.h, RT_FLAG_ARITH_MAD)
+            raise ValueError("a ray with an exactly zero direction component on a context with fused arithmetic: trace it on a strict context")
         hits = np.zeros(len(rays), L.hit_record_dtype)
         self._check(self.lib.rt_trace_closest(self.h, rays.ctypes.data, len(rays), hits.ctypes.data))
         return hits

@@ -159,3 +159,15 @@ def test_header_layout_equals_the_reference_headers(tmp_path):
                                 ("RayHit", L.ray_hit_dtype, {k: k for k in ("pos", "group_id", "local_id")})):
         for ref_field, mine in fields.items():
             assert dtype.fields[mine][1] == want[f"{name}.{ref_field}"], (name, ref_field)
+
+
+def test_python_mirror_refuses_axis_parallel_rays_on_a_fused_context():
+    """The fused slab test needs 1 / dir to be a number on every axis (include/rt_hip.h): the Python mirror says so
+    instead of letting such a ray circle until rt_trace_closest gives up."""
+    import numpy as np
+    rt = api.RayTracer.__new__(api.RayTracer)      # no context needed: the check comes before the library is called
+    rt.mad, rt.h = True, None
+    rays = np.zeros(2, L.ray_dtype)
+    rays["dir_max"][:, :3] = ((0.6, 0.8, 0.0), (0.1, 0.2, 0.3))
+    with pytest.raises(ValueError, match="zero direction component"):
+        rt.trace_closest(rays)
