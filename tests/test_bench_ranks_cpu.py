@@ -36,3 +36,18 @@ def test_two_ranks_print_one_line_with_whole_job_throughput():
     assert abs(d["mrays_primary_only"] / d["value"] - 0.75) < 1e-9
     assert "extra" not in d and "cpu_baseline" not in d   # single-GPU legs only
     assert d["roofline"]["kernel"] == "k_process_aabb" and d["roofline"]["frac"] > 0
+
+
+def test_cpu_baseline_leg_on_a_small_frame():
+    """The bench line's `cpu_baseline` object (the oracle on the host cores, a middle band of the frame) with a budget of
+    a second: the keys the line promises, a positive rate, the sample named, the arithmetic mode passed on."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    from raytracer_amd import scene as S
+    for arith in ("mad", "strict"):
+        args = argparse.Namespace(width=256, height=128, arith=arith)
+        out = bench.cpu_baseline(args, [S.BUNNY, S.BUNNY], 1.0)
+        assert set(out) == {"value", "unit", "cores", "kind", "sample"}
+        assert out["kind"] == "port" and out["unit"] == "Mrays/s" and 1 <= out["cores"] <= 16
+        assert out["value"] > 0 and "rows 56..71 of the 256x128 frame, pool 4096 slots" in out["sample"]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3: bench line, rocprofv3 kernel statistics (overlapped and serial), the other configurations, PMC passes.
+# Bench line, rocprofv3 kernel statistics (overlapped and serial), the other configurations, PMC passes; files are named r3_*.
 set -e
 o=$PWD/gpurun_out/r3p
 mkdir -p $o
