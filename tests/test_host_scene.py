@@ -142,7 +142,7 @@ def test_scene_does_not_depend_on_the_number_of_build_threads(standin_ply, monke
     built = []
     monkeypatch.setenv("RT_MESH_CACHE", "")              # parse the text: with more than one thread line by line, side by side
     monkeypatch.setenv("RT_PLY_PARALLEL_MIN", "0")       # (files this small would otherwise go through the tokenizer)
-    for threads in ("1", "2", "7"):
+    for threads in ("1", "2", "7", "16"):
         monkeypatch.setenv("RT_HOST_THREADS", threads)
         built.append(S.build_scene([S.BUNNY, standin_ply], 96, 64, 8192, aabb_threshold=16))
     for sc in built[1:]:
